@@ -1,0 +1,919 @@
+/*
+ * cpmpc_oracle.c -- CPU restatement ("oracle") of the cart-pole MPC hot path.  fp64, scalar, C99.
+ *
+ * TEST INFRASTRUCTURE ONLY -- see cpmpc_oracle.h for the rules and the parity status
+ * (dynamics/RK4 pinned; SQP solver: parity unpinned vs. mini_opt, which is absent).
+ *
+ * Every function cites the reference file:line it follows (paths relative to /root/reference).
+ * Written from the reference's behaviour and from the Lagrangian specification; no reference
+ * source is copied.
+ */
+#include "cpmpc_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+/* ------------------------------------------------------------------------------------------- */
+/* defaults                                                                                     */
+/* ------------------------------------------------------------------------------------------- */
+
+/* optimization/optimization.hpp:12-48 */
+void orc_default_opt_params(orc_opt_params* p) {
+  p->control_dt = 0.01;
+  p->window_length = 40;
+  p->state_spacing = 10;
+  p->max_iterations = 8;
+  p->relative_exit_tol = 1.0e-5;
+  p->absolute_first_derivative_tol = 1.0e-6;
+  p->equality_penalty_initial = 1.0;
+  p->u_guess_sinusoid_amplitude = 10.0;
+  p->u_cost_weight = 0.1;
+  p->u_derivative_cost_weight = 0.1;
+  p->b_x_final_cost_weight = 150.0;
+  p->th_final_cost_weight = -1.0;
+  p->b_x_dot_final_cost_weight = -1.0;
+  p->th_dot_final_cost_weight = -1.0;
+}
+
+/* This repo's solver specification; max_line_search_iterations from
+ * optimization/optimization.cc:76, clamps from optimization.cc:320,327. */
+void orc_default_solver_opts(orc_solver_opts* o) {
+  o->max_line_search_iterations = 5;
+  o->armijo_c1 = 1.0e-4;
+  o->ls_shrink_max = 0.5;
+  o->ls_shrink_min = 0.1;
+  o->penalty_rho = 0.1;
+  o->lambda_initial = 0.0;
+  o->lambda_failure_init = 1.0e-2;
+  o->lambda_scale_up = 10.0;
+  o->lambda_scale_down = 0.1;
+  o->lambda_min = 1.0e-8;
+  o->lambda_max = 1.0e6;
+  o->b_x_limit = 5.0;
+  o->u_limit = 300.0;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* L0: dynamics                                                                                 */
+/* ------------------------------------------------------------------------------------------- */
+
+/*
+ * Forward dynamics of the cart + point-mass pole.
+ * Follows optimization/single_pendulum_dynamics.hpp:13-186 (machine generated) by re-deriving the
+ * Euler-Lagrange equations of symbolic/dynamics_single.py:58-143:
+ *
+ *   p1 = (b_x + l cos th, l sin th),  T = 1/2 m_b b_x'^2 + 1/2 m_1 |p1'|^2,  V = g m_1 l sin th
+ *
+ *   [ m_b+m_1      -m_1 l sin th ] [b_x''] = [ F_b  ]
+ *   [ -m_1 l sin th   m_1 l^2    ] [th'' ]   [ F_th ]
+ *
+ *   F_b  = u + f_base.x + f_mass.x + F_fric + F_spring - dD/db_x' + m_1 l th'^2 cos th
+ *   F_th = l(-f_mass.x sin th + f_mass.y cos th) - g m_1 l cos th - dD/dth'
+ *   F_fric   = -mu_b (m_1+m_b) g tanh(b_x' / max(v_mu_b, 1e-6))      (dynamics_single.py:100-103)
+ *   D        = (1/6) c_d |p1'|^3   if |p1'|^2 > 0 else 0              (dynamics_single.py:105-111)
+ *   F_spring = -k_s max(0, b_x - x_s) + k_s max(0, -x_s - b_x)        (dynamics_single.py:113-115)
+ *
+ * f_base.y never enters the equations (the base moves on x only), as in the generated header.
+ * Jx (4x4 row-major) and Ju (4) are optional, like the generated function's J_x / J_u.
+ */
+void orc_dynamics(const double params[9], const double x[4], double u, const double f_base[2],
+                  const double f_mass[2], double f_out[4], double* Jx, double* Ju) {
+  const double m_b = params[0], m_1 = params[1], L = params[2], g = params[3];
+  const double mu = params[4], v_mu_in = params[5], cd = params[6], xs = params[7], ks = params[8];
+  const double bx = x[0], th = x[1], v = x[2], w = x[3];
+  const double s = sin(th), c = cos(th);
+  const double mt = m_1 + m_b;
+
+  /* bumper springs; the comparisons are strict `0 < arg` as in the generated branches */
+  const double e_r = bx - xs;
+  const double e_l = -(bx + xs);
+  const int on_r = 0.0 < e_r;
+  const int on_l = 0.0 < e_l;
+  const double F_s = ks * ((on_l ? e_l : 0.0) - (on_r ? e_r : 0.0));
+  const double dFs_dbx = ks * ((on_l ? -1.0 : 0.0) - (on_r ? 1.0 : 0.0));
+
+  /* smoothed Coulomb friction on the base */
+  const double v_mu = (1.0e-6 < v_mu_in) ? v_mu_in : 1.0e-6;
+  const double inv_v_mu = 1.0 / v_mu;
+  const double tv = tanh(v * inv_v_mu);
+  const double fr = (mt * mu) * -g;
+  const double F_f = tv * fr;
+  const double dFf_dv = inv_v_mu * (1.0 - tv * tv) * fr;
+
+  /* air drag on the pole mass: velocity of the mass */
+  const double vx = v - L * w * s;
+  const double vy = L * w * c;
+  const double n2 = vx * vx + vy * vy;
+  const double n = sqrt(n2);
+  const int on_d = 0.0 < n2;
+  const double e = c * vy - s * vx; /* (1/l) * p1' . dp1'/dth' */
+  const double Dx = on_d ? 0.5 * cd * n * vx : 0.0;
+  const double Dth = on_d ? 0.5 * cd * L * n * e : 0.0;
+
+  const double F_b = u + f_base[0] + f_mass[0] + F_f + F_s - Dx + m_1 * L * w * w * c;
+  const double F_th = L * (-f_mass[0] * s + f_mass[1] * c) - g * m_1 * L * c - Dth;
+
+  const double den = mt - m_1 * s * s;
+  const double inv_den = 1.0 / den;
+  const double sl = s / L;
+  const double kap = mt / (m_1 * L * L);
+  const double N_x = F_b + sl * F_th;
+  const double N_th = sl * F_b + kap * F_th;
+  const double a_x = N_x * inv_den;
+  const double a_th = N_th * inv_den;
+
+  f_out[0] = v;
+  f_out[1] = w;
+  f_out[2] = a_x;
+  f_out[3] = a_th;
+
+  if (Jx) {
+    /* partials with respect to (th, v, w) */
+    const double dvx[3] = {-L * w * c, 1.0, -L * s};
+    const double dvy[3] = {-L * w * s, 0.0, L * c};
+    const double de[3] = {-s * vy - c * vx, -s, L};
+    double dDx[3] = {0, 0, 0}, dDth[3] = {0, 0, 0};
+    if (on_d) {
+      const double inv_n = 1.0 / n;
+      for (int i = 0; i < 3; ++i) {
+        const double dn = (vx * dvx[i] + vy * dvy[i]) * inv_n;
+        dDx[i] = 0.5 * cd * (dn * vx + n * dvx[i]);
+        dDth[i] = 0.5 * cd * L * (dn * e + n * de[i]);
+      }
+    }
+    const double dFb[3] = {-dDx[0] - m_1 * L * w * w * s, dFf_dv - dDx[1],
+                           -dDx[2] + 2.0 * m_1 * L * w * c};
+    const double dFth[3] = {L * (-f_mass[0] * c - f_mass[1] * s) + g * m_1 * L * s - dDth[0],
+                            -dDth[1], -dDth[2]};
+    const double dden_dth = -2.0 * m_1 * s * c;
+    const double cl = c / L;
+    const double dNx[3] = {dFb[0] + cl * F_th + sl * dFth[0], dFb[1] + sl * dFth[1],
+                           dFb[2] + sl * dFth[2]};
+    const double dNth[3] = {cl * F_b + sl * dFb[0] + kap * dFth[0], sl * dFb[1] + kap * dFth[1],
+                            sl * dFb[2] + kap * dFth[2]};
+    /* rows 0,1: d(b_x', th')/dx  (single_pendulum_dynamics.hpp:159-166) */
+    for (int i = 0; i < 16; ++i) Jx[i] = 0.0;
+    Jx[0 * 4 + 2] = 1.0;
+    Jx[1 * 4 + 3] = 1.0;
+    Jx[2 * 4 + 0] = dFs_dbx * inv_den;
+    Jx[2 * 4 + 1] = (dNx[0] - a_x * dden_dth) * inv_den;
+    Jx[2 * 4 + 2] = dNx[1] * inv_den;
+    Jx[2 * 4 + 3] = dNx[2] * inv_den;
+    Jx[3 * 4 + 0] = sl * dFs_dbx * inv_den;
+    Jx[3 * 4 + 1] = (dNth[0] - a_th * dden_dth) * inv_den;
+    Jx[3 * 4 + 2] = dNth[1] * inv_den;
+    Jx[3 * 4 + 3] = dNth[2] * inv_den;
+  }
+  if (Ju) {
+    /* single_pendulum_dynamics.hpp:179-184 */
+    Ju[0] = 0.0;
+    Ju[1] = 0.0;
+    Ju[2] = inv_den;
+    Ju[3] = sl * inv_den;
+  }
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* L1: integrators                                                                              */
+/* ------------------------------------------------------------------------------------------- */
+
+static void mat4_mul(const double* a, const double* b, double* out) { /* out = a*b, 4x4 */
+  double t[16];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      double acc = 0.0;
+      for (int k = 0; k < 4; ++k) acc += a[i * 4 + k] * b[k * 4 + j];
+      t[i * 4 + j] = acc;
+    }
+  memcpy(out, t, sizeof t);
+}
+
+static void mat4_vec(const double* a, const double* v, double* out) {
+  double t[4];
+  for (int i = 0; i < 4; ++i) {
+    double acc = 0.0;
+    for (int k = 0; k < 4; ++k) acc += a[i * 4 + k] * v[k];
+    t[i] = acc;
+  }
+  memcpy(out, t, sizeof t);
+}
+
+/* optimization/integration.hpp:52-62 */
+void orc_rk4_no_jacobians(const double params[9], const double x[4], double u, double h,
+                          const double f_base[2], const double f_mass[2], double x_new[4]) {
+  double k1[4], k2[4], k3[4], k4[4], xt[4];
+  orc_dynamics(params, x, u, f_base, f_mass, k1, NULL, NULL);
+  for (int i = 0; i < 4; ++i) xt[i] = x[i] + k1[i] * h / 2.0;
+  orc_dynamics(params, xt, u, f_base, f_mass, k2, NULL, NULL);
+  for (int i = 0; i < 4; ++i) xt[i] = x[i] + k2[i] * h / 2.0;
+  orc_dynamics(params, xt, u, f_base, f_mass, k3, NULL, NULL);
+  for (int i = 0; i < 4; ++i) xt[i] = x[i] + k3[i] * h;
+  orc_dynamics(params, xt, u, f_base, f_mass, k4, NULL, NULL);
+  for (int i = 0; i < 4; ++i)
+    x_new[i] = x[i] + (h / 6.0) * (k1[i] + k2[i] * 2.0 + k3[i] * 2.0 + k4[i]);
+}
+
+/* optimization/integration.hpp:13-49: state + A = dx+/dx + B = dx+/du by the stage chain rule */
+void orc_rk4(const double params[9], const double x[4], double u, double h,
+             const double f_base[2], const double f_mass[2], double x_new[4], double A[16],
+             double B[4]) {
+  double k1[4], k2[4], k3[4], k4[4], xt[4];
+  double K1[16], K2[16], K3[16], K4[16]; /* stage Jacobians at the stage arguments */
+  double U1[4], U2[4], U3[4], U4[4];
+  orc_dynamics(params, x, u, f_base, f_mass, k1, K1, U1);
+  for (int i = 0; i < 4; ++i) xt[i] = x[i] + k1[i] * h / 2.0;
+  orc_dynamics(params, xt, u, f_base, f_mass, k2, K2, U2);
+  for (int i = 0; i < 4; ++i) xt[i] = x[i] + k2[i] * h / 2.0;
+  orc_dynamics(params, xt, u, f_base, f_mass, k3, K3, U3);
+  for (int i = 0; i < 4; ++i) xt[i] = x[i] + k3[i] * h;
+  orc_dynamics(params, xt, u, f_base, f_mass, k4, K4, U4);
+  for (int i = 0; i < 4; ++i)
+    x_new[i] = x[i] + (h / 6.0) * (k1[i] + k2[i] * 2.0 + k3[i] * 2.0 + k4[i]);
+
+  /* integration.hpp:36-39: k2_D_x = K2 (I + K1 h/2), k3_D_x = K3 (I + k2_D_x h/2), ... */
+  double T[16], D2[16], D3[16], D4[16];
+  for (int i = 0; i < 16; ++i) T[i] = K1[i] * h / 2.0 + ((i % 5 == 0) ? 1.0 : 0.0);
+  mat4_mul(K2, T, D2);
+  for (int i = 0; i < 16; ++i) T[i] = D2[i] * h / 2.0 + ((i % 5 == 0) ? 1.0 : 0.0);
+  mat4_mul(K3, T, D3);
+  for (int i = 0; i < 16; ++i) T[i] = D3[i] * h + ((i % 5 == 0) ? 1.0 : 0.0);
+  mat4_mul(K4, T, D4);
+
+  /* integration.hpp:41-43 */
+  double d2[4], d3[4], d4[4], t4[4];
+  mat4_vec(K2, U1, t4);
+  for (int i = 0; i < 4; ++i) d2[i] = t4[i] * (h / 2.0) + U2[i];
+  mat4_vec(K3, d2, t4);
+  for (int i = 0; i < 4; ++i) d3[i] = t4[i] * (h / 2.0) + U3[i];
+  mat4_vec(K4, d3, t4);
+  for (int i = 0; i < 4; ++i) d4[i] = t4[i] * h + U4[i];
+
+  /* integration.hpp:45-46 */
+  for (int i = 0; i < 16; ++i)
+    A[i] = ((i % 5 == 0) ? 1.0 : 0.0) + (h / 6.0) * (K1[i] + D2[i] * 2.0 + D3[i] * 2.0 + D4[i]);
+  for (int i = 0; i < 4; ++i) B[i] = (h / 6.0) * (U1[i] + d2[i] * 2.0 + d3[i] * 2.0 + d4[i]);
+}
+
+/* optimization/integration.hpp:65-73: map to (-pi, pi] */
+double orc_mod_pi(double angle) {
+  const double pi = M_PI;
+  const double two_pi = 2 * pi;
+  angle = fmod(angle, two_pi);
+  angle += (angle < 0) * two_pi;
+  angle -= (angle > pi) * two_pi;
+  return angle;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* L3: shooting constraint, problem assembly                                                    */
+/* ------------------------------------------------------------------------------------------- */
+
+static const double kZero2[2] = {0.0, 0.0};
+
+/* optimization/optimization.cc:99-160.  The angle is wrapped only at the END of the interval here
+ * (line 139), unlike FillInitialGuess / ComputePredictedStates which wrap after every step. */
+void orc_shooting_constraint(const double params[9], int spacing, double dt, const double* vars,
+                             double err[4], double* J) {
+  const double* x_k = vars;
+  const double* x_kp1 = vars + 4;
+  const double* u_k = vars + 8;
+  double x[4] = {x_k[0], x_k[1], x_k[2], x_k[3]};
+  double* As = NULL;
+  double* Bs = NULL;
+  if (J) {
+    As = (double*)malloc(sizeof(double) * 16 * (size_t)spacing);
+    Bs = (double*)malloc(sizeof(double) * 4 * (size_t)spacing);
+    for (int i = 0; i < spacing; ++i) {
+      double xn[4];
+      orc_rk4(params, x, u_k[i], dt, kZero2, kZero2, xn, As + 16 * i, Bs + 4 * i);
+      memcpy(x, xn, sizeof xn);
+    }
+  } else {
+    for (int i = 0; i < spacing; ++i) {
+      double xn[4];
+      orc_rk4_no_jacobians(params, x, u_k[i], dt, kZero2, kZero2, xn);
+      memcpy(x, xn, sizeof xn);
+    }
+  }
+  x[1] = orc_mod_pi(x[1]);
+
+  if (J) {
+    const int cols = 8 + spacing;
+    double Phi[16];
+    for (int i = 0; i < 16; ++i) Phi[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    /* optimization.cc:145-151: backward chain rule */
+    for (int i = spacing - 1; i >= 0; --i) {
+      double g4[4];
+      mat4_vec(Phi, Bs + 4 * i, g4);
+      for (int r = 0; r < 4; ++r) J[r * cols + 8 + i] = g4[r];
+      mat4_mul(Phi, As + 16 * i, Phi);
+    }
+    for (int r = 0; r < 4; ++r)
+      for (int cI = 0; cI < 4; ++cI) {
+        J[r * cols + cI] = Phi[r * 4 + cI];
+        J[r * cols + 4 + cI] = (r == cI) ? -1.0 : 0.0;
+      }
+    free(As);
+    free(Bs);
+  }
+  for (int i = 0; i < 4; ++i) err[i] = x[i] - x_kp1[i];
+  err[1] = orc_mod_pi(err[1]);
+}
+
+static int num_states(const orc_opt_params* p) { /* optimization.hpp:52 */
+  return (int)(p->window_length / p->state_spacing) + 1;
+}
+
+/* terminal weights in BuildProblem order (optimization.cc:236-267) */
+static void terminal_spec(const orc_opt_params* p, double set_point, double w[4], double tgt[4]) {
+  w[0] = p->b_x_final_cost_weight;
+  w[1] = p->th_final_cost_weight;
+  w[2] = p->b_x_dot_final_cost_weight;
+  w[3] = p->th_dot_final_cost_weight;
+  tgt[0] = set_point;
+  tgt[1] = M_PI / 2;
+  tgt[2] = 0.0;
+  tgt[3] = 0.0;
+}
+
+void orc_problem_shape(const orc_opt_params* p, int* dim, int* n_eq, int* n_cost) {
+  const int S = num_states(p);
+  const int N = (int)p->window_length;
+  double w[4], tgt[4];
+  terminal_spec(p, 0.0, w, tgt);
+  int ne = 4 * (S - 1) + 4, nc = 0;
+  for (int t = 0; t < 4; ++t) {
+    if (w[t] >= 0.0)
+      ++nc;
+    else
+      ++ne;
+  }
+  if (p->u_derivative_cost_weight > 0.0) nc += (N - 1) + 1;
+  if (p->u_cost_weight > 0.0) nc += N;
+  if (dim) *dim = 4 * S + N; /* optimization.cc:204-205 */
+  if (n_eq) *n_eq = ne;
+  if (n_cost) *n_cost = nc;
+}
+
+/* optimization/optimization.cc:194-301 (BuildProblem) evaluated at z.
+ * Variable layout (MapKey, optimization.cc:27-37): state t of shooting node s at 4s+t, u_k at 4S+k. */
+void orc_problem_eval(const orc_opt_params* p, const double dyn[9], const double x_current[4],
+                      double set_point, double u_prev, const double* z, double* r_cost,
+                      double* c_eq, double* J_cost, double* A_eq) {
+  const int S = num_states(p);
+  const int N = (int)p->window_length;
+  const int sp = (int)p->state_spacing;
+  int dim, n_eq, n_cost;
+  orc_problem_shape(p, &dim, &n_eq, &n_cost);
+  if (J_cost) memset(J_cost, 0, sizeof(double) * (size_t)n_cost * (size_t)dim);
+  if (A_eq) memset(A_eq, 0, sizeof(double) * (size_t)n_eq * (size_t)dim);
+
+  int re = 0, rc = 0;
+  double* vars = (double*)malloc(sizeof(double) * (size_t)(8 + sp));
+  double* Jloc = A_eq ? (double*)malloc(sizeof(double) * 4 * (size_t)(8 + sp)) : NULL;
+
+  /* shooting equality constraints between adjacent states (optimization.cc:208-225) */
+  for (int s = 0; s + 1 < S; ++s) {
+    for (int t = 0; t < 4; ++t) {
+      vars[t] = z[4 * s + t];
+      vars[4 + t] = z[4 * (s + 1) + t];
+    }
+    for (int k = 0; k < sp; ++k) vars[8 + k] = z[4 * S + sp * s + k];
+    double err[4];
+    orc_shooting_constraint(dyn, sp, p->control_dt, vars, err, Jloc);
+    for (int r = 0; r < 4; ++r) {
+      c_eq[re + r] = err[r];
+      if (A_eq) {
+        double* row = A_eq + (size_t)(re + r) * dim;
+        for (int t = 0; t < 4; ++t) {
+          row[4 * s + t] = Jloc[r * (8 + sp) + t];
+          row[4 * (s + 1) + t] = Jloc[r * (8 + sp) + 4 + t];
+        }
+        for (int k = 0; k < sp; ++k) row[4 * S + sp * s + k] = Jloc[r * (8 + sp) + 8 + k];
+      }
+    }
+    re += 4;
+  }
+  free(vars);
+  free(Jloc);
+
+  /* equality constraint on the initial state, weight 1, angle wrapped (optimization.cc:228-232) */
+  for (int t = 0; t < 4; ++t) {
+    double d = z[t] - x_current[t];
+    if (t == 1) d = orc_mod_pi(d);
+    c_eq[re] = d * 1.0;
+    if (A_eq) A_eq[(size_t)re * dim + t] = 1.0;
+    ++re;
+  }
+
+  /* terminal rows: cost if weight >= 0 else equality with weight 1 (optimization.cc:236-267) */
+  double w[4], tgt[4];
+  terminal_spec(p, set_point, w, tgt);
+  for (int t = 0; t < 4; ++t) {
+    const int idx = 4 * (S - 1) + t;
+    double d = z[idx] - tgt[t];
+    if (t == 1) d = orc_mod_pi(d);
+    if (w[t] >= 0.0) {
+      r_cost[rc] = d * w[t];
+      if (J_cost) J_cost[(size_t)rc * dim + idx] = w[t];
+      ++rc;
+    } else {
+      c_eq[re] = d * 1.0;
+      if (A_eq) A_eq[(size_t)re * dim + idx] = 1.0;
+      ++re;
+    }
+  }
+
+  /* penalty on the derivative of the control inputs (optimization.cc:270-294) */
+  if (p->u_derivative_cost_weight > 0.0) {
+    const double wd = p->u_derivative_cost_weight;
+    for (int k = 0; k + 1 < N; ++k) {
+      r_cost[rc] = (z[4 * S + k] - z[4 * S + k + 1]) * wd;
+      if (J_cost) {
+        J_cost[(size_t)rc * dim + 4 * S + k] = wd;
+        J_cost[(size_t)rc * dim + 4 * S + k + 1] = -wd;
+      }
+      ++rc;
+    }
+    r_cost[rc] = (z[4 * S + 0] - u_prev) * wd;
+    if (J_cost) J_cost[(size_t)rc * dim + 4 * S + 0] = wd;
+    ++rc;
+  }
+  /* penalty on the control inputs (optimization.cc:296-301) */
+  if (p->u_cost_weight > 0.0) {
+    const double wu = p->u_cost_weight;
+    for (int k = 0; k < N; ++k) {
+      r_cost[rc] = (z[4 * S + k] - 0.0) * wu;
+      if (J_cost) J_cost[(size_t)rc * dim + 4 * S + k] = wu;
+      ++rc;
+    }
+  }
+}
+
+static double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* optimization/optimization.cc:309-329 */
+void orc_retract(const orc_opt_params* p, const orc_solver_opts* o, const double* z,
+                 const double* dz, double alpha, double* z_out) {
+  const int S = num_states(p);
+  const int N = (int)p->window_length;
+  const int dim = 4 * S + N;
+  for (int i = 0; i < dim; ++i) z_out[i] = z[i] + dz[i] * alpha;
+  for (int s = 0; s < S; ++s) {
+    z_out[4 * s + 1] = orc_mod_pi(z_out[4 * s + 1]);
+    z_out[4 * s + 0] = clampd(z_out[4 * s + 0], -o->b_x_limit, o->b_x_limit);
+  }
+  for (int k = 0; k < N; ++k) z_out[4 * S + k] = clampd(z_out[4 * S + k], -o->u_limit, o->u_limit);
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* L2: the SQP specified by this repo (stands where mini_opt stands in the reference)          */
+/* ------------------------------------------------------------------------------------------- */
+
+/* Dense LU with partial pivoting; solves K x = b in place (b -> x).  Returns nonzero if singular. */
+static int lu_solve(int n, double* K, double* b) {
+  double kmax = 0.0;
+  for (int i = 0; i < n * n; ++i) {
+    const double a = fabs(K[i]);
+    if (a > kmax) kmax = a;
+  }
+  if (!(kmax > 0.0) || !isfinite(kmax)) return 1;
+  const double tiny = 0.0; /* only an exactly singular or non-finite pivot is a failure */
+  for (int col = 0; col < n; ++col) {
+    int piv = col;
+    double best = fabs(K[col * n + col]);
+    for (int r = col + 1; r < n; ++r) {
+      const double a = fabs(K[r * n + col]);
+      if (a > best) {
+        best = a;
+        piv = r;
+      }
+    }
+    if (!(best > tiny)) return 1;
+    if (piv != col) {
+      for (int j = 0; j < n; ++j) {
+        const double t = K[col * n + j];
+        K[col * n + j] = K[piv * n + j];
+        K[piv * n + j] = t;
+      }
+      const double t = b[col];
+      b[col] = b[piv];
+      b[piv] = t;
+    }
+    const double inv = 1.0 / K[col * n + col];
+    for (int r = col + 1; r < n; ++r) {
+      const double f = K[r * n + col] * inv;
+      if (f == 0.0) continue;
+      for (int j = col + 1; j < n; ++j) K[r * n + j] -= f * K[col * n + j];
+      b[r] -= f * b[col];
+    }
+  }
+  for (int r = n - 1; r >= 0; --r) {
+    double acc = b[r];
+    for (int j = r + 1; j < n; ++j) acc -= K[r * n + j] * b[j];
+    b[r] = acc / K[r * n + r];
+  }
+  return 0;
+}
+
+/*
+ * min_dz 1/2 |J dz + r|^2 + 1/2 lambda |dz_u|^2   s.t.  A dz + c = 0
+ * on the full variable space, via the dense KKT system
+ *     [ J^T J + lambda E_u   A^T ] [dz]   [ -J^T r ]
+ *     [ A                    0   ] [nu] = [ -c     ]
+ * (E_u selects the n_u control variables, which are last in z).  This is the role mini_opt's QP
+ * plays at optimization.cc:81; the method (dense, full-space) is deliberately different from the
+ * product's structure-exploiting per-lane solve so that the two check each other.
+ */
+int orc_qp_solve(int dim, int n_eq, int n_cost, int n_u, const double* J_cost, const double* r_cost,
+                 const double* A_eq, const double* c_eq, double lambda, double* dz) {
+  const int n = dim + n_eq;
+  double* K = (double*)calloc((size_t)n * (size_t)n, sizeof(double));
+  double* b = (double*)calloc((size_t)n, sizeof(double));
+  for (int r = 0; r < n_cost; ++r) {
+    const double* row = J_cost + (size_t)r * dim;
+    for (int i = 0; i < dim; ++i) {
+      const double a = row[i];
+      if (a == 0.0) continue;
+      b[i] -= a * r_cost[r];
+      for (int j = 0; j < dim; ++j) K[(size_t)i * n + j] += a * row[j];
+    }
+  }
+  for (int k = dim - n_u; k < dim; ++k) K[(size_t)k * n + k] += lambda;
+  for (int r = 0; r < n_eq; ++r) {
+    for (int j = 0; j < dim; ++j) {
+      const double a = A_eq[(size_t)r * dim + j];
+      K[(size_t)(dim + r) * n + j] = a;
+      K[(size_t)j * n + dim + r] = a;
+    }
+    b[dim + r] = -c_eq[r];
+  }
+  const int bad = lu_solve(n, K, b);
+  if (!bad) {
+    for (int i = 0; i < dim; ++i) {
+      dz[i] = b[i];
+      if (!isfinite(b[i])) {
+        free(K);
+        free(b);
+        return 2;
+      }
+    }
+  }
+  free(K);
+  free(b);
+  return bad;
+}
+
+static double half_sq_norm(const double* v, int n) {
+  double acc = 0.0;
+  for (int i = 0; i < n; ++i) acc += v[i] * v[i];
+  return 0.5 * acc;
+}
+static double l1_norm(const double* v, int n) {
+  double acc = 0.0;
+  for (int i = 0; i < n; ++i) acc += fabs(v[i]);
+  return acc;
+}
+
+/*
+ * The SQP iteration.  Stands where
+ * mini_opt::ConstrainedNonlinearLeastSquares::Solve stands (optimization.cc:73-81):
+ *   per iteration: linearise -> QP -> l1-merit penalty update -> Armijo backtracking with the
+ *   retraction -> accept (decay lambda) or reject (raise lambda); exits on first-order tolerance,
+ *   relative decrease, QP failure, lambda overflow, or max_iterations.
+ */
+int orc_solve(const orc_opt_params* p, const orc_solver_opts* o_in, const double dyn[9],
+              const double x_current[4], double set_point, double u_prev, const double* guess,
+              double* z_out, orc_solver_summary* summary) {
+  orc_solver_opts o_def;
+  if (!o_in) {
+    orc_default_solver_opts(&o_def);
+    o_in = &o_def;
+  }
+  const orc_solver_opts* o = o_in;
+  int dim, n_eq, n_cost;
+  orc_problem_shape(p, &dim, &n_eq, &n_cost);
+  const int N = (int)p->window_length;
+
+  double* z = (double*)malloc(sizeof(double) * (size_t)dim);
+  double* zt = (double*)malloc(sizeof(double) * (size_t)dim);
+  double* dz = (double*)malloc(sizeof(double) * (size_t)dim);
+  double* r = (double*)malloc(sizeof(double) * (size_t)(n_cost > 0 ? n_cost : 1));
+  double* c = (double*)malloc(sizeof(double) * (size_t)n_eq);
+  double* rt = (double*)malloc(sizeof(double) * (size_t)(n_cost > 0 ? n_cost : 1));
+  double* ct = (double*)malloc(sizeof(double) * (size_t)n_eq);
+  double* J = (double*)malloc(sizeof(double) * (size_t)(n_cost > 0 ? n_cost : 1) * (size_t)dim);
+  double* A = (double*)malloc(sizeof(double) * (size_t)n_eq * (size_t)dim);
+  memcpy(z, guess, sizeof(double) * (size_t)dim);
+
+  double lambda = o->lambda_initial;
+  double mu = p->equality_penalty_initial;
+  int term = ORC_TERM_MAX_ITERATIONS;
+  int iters = 0, ls_evals = 0, failed = 0;
+  double f0 = 0.0, cn0 = 0.0, f_last = 0.0, cn_last = 0.0;
+
+  for (int iter = 0; iter < (int)p->max_iterations; ++iter) {
+    orc_problem_eval(p, dyn, x_current, set_point, u_prev, z, r, c, J, A);
+    const double f = half_sq_norm(r, n_cost);
+    const double cn = l1_norm(c, n_eq);
+    if (iter == 0) {
+      f0 = f;
+      cn0 = cn;
+    }
+    f_last = f;
+    cn_last = cn;
+    if (!isfinite(f) || !isfinite(cn)) {
+      term = ORC_TERM_NON_FINITE;
+      break;
+    }
+    ++iters;
+    if (orc_qp_solve(dim, n_eq, n_cost, N, J, r, A, c, lambda, dz) != 0) {
+      term = ORC_TERM_QP_INDEFINITE;
+      break;
+    }
+    /* directional derivative of the cost and Gauss-Newton curvature along dz */
+    double gd = 0.0, curv = 0.0;
+    for (int i = 0; i < n_cost; ++i) {
+      double jd = 0.0;
+      const double* row = J + (size_t)i * dim;
+      for (int j = 0; j < dim; ++j) jd += row[j] * dz[j];
+      gd += r[i] * jd;
+      curv += jd * jd;
+    }
+    for (int k = dim - N; k < dim; ++k) curv += lambda * dz[k] * dz[k];
+
+    /* l1-merit penalty, Nocedal & Wright (18.36) with sigma = 1 */
+    if (cn > 0.0) {
+      const double mu_req = (gd + 0.5 * curv) / ((1.0 - o->penalty_rho) * cn);
+      if (mu < mu_req) mu = mu_req;
+    }
+    const double D = gd - mu * cn;
+    const double phi0 = f + mu * cn;
+    /* first-order test: the step is still tried (and kept if it passes Armijo) before exiting */
+    const int first_order = fabs(D) < p->absolute_first_derivative_tol;
+
+    /* Armijo backtracking along the retraction; the next trial step is the minimiser of the
+     * quadratic through phi(0), phi'(0), phi(alpha), safeguarded to [ls_shrink_min, ls_shrink_max]
+     * times the current step */
+    double alpha = 1.0;
+    int accepted = 0;
+    double phi_t = 0.0, f_t = 0.0, cn_t = 0.0;
+    for (int t = 0; t < o->max_line_search_iterations; ++t) {
+      orc_retract(p, o, z, dz, alpha, zt);
+      orc_problem_eval(p, dyn, x_current, set_point, u_prev, zt, rt, ct, NULL, NULL);
+      ++ls_evals;
+      f_t = half_sq_norm(rt, n_cost);
+      cn_t = l1_norm(ct, n_eq);
+      phi_t = f_t + mu * cn_t;
+      if (phi_t <= phi0 + o->armijo_c1 * alpha * D) { /* false for NaN */
+        accepted = 1;
+        break;
+      }
+      {
+        const double denom = 2.0 * (phi_t - phi0 - D * alpha);
+        double a_new = (denom > 0.0) ? (-D * alpha * alpha / denom) : (o->ls_shrink_max * alpha);
+        if (!(a_new >= o->ls_shrink_min * alpha)) a_new = o->ls_shrink_min * alpha;
+        if (a_new > o->ls_shrink_max * alpha) a_new = o->ls_shrink_max * alpha;
+        alpha = a_new;
+      }
+    }
+    if (accepted) {
+      memcpy(z, zt, sizeof(double) * (size_t)dim);
+      f_last = f_t;
+      cn_last = cn_t;
+      lambda *= o->lambda_scale_down;
+      if (lambda < o->lambda_min) lambda = 0.0;
+    }
+    if (first_order) {
+      term = ORC_TERM_SATISFIED_FIRST_ORDER_TOL;
+      break;
+    }
+    if (accepted) {
+      if ((phi0 - phi_t) < p->relative_exit_tol * phi0) {
+        term = ORC_TERM_SATISFIED_RELATIVE_TOL;
+        break;
+      }
+    } else {
+      ++failed;
+      lambda = (lambda > 0.0) ? lambda * o->lambda_scale_up : o->lambda_failure_init;
+      if (lambda > o->lambda_max) {
+        term = ORC_TERM_MAX_LAMBDA;
+        break;
+      }
+    }
+  }
+
+  if (z_out) memcpy(z_out, z, sizeof(double) * (size_t)dim);
+  if (summary) {
+    summary->termination_state = term;
+    summary->iterations = iters;
+    summary->line_search_evals = ls_evals;
+    summary->failed_steps = failed;
+    summary->initial_cost = f0;
+    summary->initial_eq_l1 = cn0;
+    summary->final_cost = f_last;
+    summary->final_eq_l1 = cn_last;
+    summary->final_penalty = mu;
+    summary->final_lambda = lambda;
+  }
+  free(z);
+  free(zt);
+  free(dz);
+  free(r);
+  free(c);
+  free(rt);
+  free(ct);
+  free(J);
+  free(A);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* L3: Optimization::Step                                                                       */
+/* ------------------------------------------------------------------------------------------- */
+
+struct orc_optimization {
+  orc_opt_params params;
+  orc_solver_opts opts;
+  int has_prev;
+  int dim;
+  double* prev; /* previous_solution_ (optimization.hpp:107) */
+};
+
+/* optimization/optimization.cc:13-22: the constructor's preconditions */
+orc_optimization* orc_opt_create(const orc_opt_params* p, const orc_solver_opts* o) {
+  if (!(p->control_dt > 0)) return NULL;
+  if (!(p->window_length >= 1)) return NULL;
+  if (p->state_spacing == 0 || p->window_length % p->state_spacing != 0) return NULL;
+  if (!(p->max_iterations >= 1)) return NULL;
+  if (!(p->u_cost_weight >= 0.0)) return NULL;
+  if (!(p->u_derivative_cost_weight >= 0.0)) return NULL;
+  orc_optimization* opt = (orc_optimization*)calloc(1, sizeof(orc_optimization));
+  opt->params = *p;
+  if (o)
+    opt->opts = *o;
+  else
+    orc_default_solver_opts(&opt->opts);
+  orc_problem_shape(p, &opt->dim, NULL, NULL);
+  opt->prev = (double*)calloc((size_t)opt->dim, sizeof(double));
+  opt->has_prev = 0;
+  return opt;
+}
+
+void orc_opt_destroy(orc_optimization* opt) {
+  if (!opt) return;
+  free(opt->prev);
+  free(opt);
+}
+
+void orc_opt_reset(orc_optimization* opt) { opt->has_prev = 0; } /* optimization.hpp:83 */
+
+/* optimization.hpp:86-89 */
+void orc_opt_set_previous_solution(orc_optimization* opt, const double* z, int n) {
+  if (n != opt->dim) {
+    opt->has_prev = 0;
+    return;
+  }
+  memcpy(opt->prev, z, sizeof(double) * (size_t)n);
+  opt->has_prev = 1;
+}
+
+int orc_opt_has_previous_solution(const orc_optimization* opt) { return opt->has_prev; }
+
+/* optimization/optimization.cc:39-97 */
+int orc_opt_step(orc_optimization* opt, const double state[4], const double dyn[9],
+                 double set_point, double* u_out, double* predicted_out, double* guess_out,
+                 double* z_out, orc_solver_summary* summary) {
+  const orc_opt_params* p = &opt->params;
+  const int S = num_states(p);
+  const int N = (int)p->window_length;
+  const int sp = (int)p->state_spacing;
+  const int dim = opt->dim;
+
+  /* BuildProblem runs first and reads u_prev from the not-yet-overwritten previous solution
+   * (optimization.cc:44,288-291) */
+  const double u_prev = opt->has_prev ? opt->prev[4 * S + 0] : 0.0;
+
+  double* guess = (double*)calloc((size_t)dim, sizeof(double));
+  if (opt->has_prev) {
+    /* optimization.cc:50-57: copy, overwrite x0, shift controls left by one */
+    memcpy(guess, opt->prev, sizeof(double) * (size_t)dim);
+    for (int t = 0; t < 4; ++t) guess[t] = state[t];
+    for (int k = 0; k + 1 < N; ++k) guess[4 * S + k] = guess[4 * S + k + 1];
+  } else {
+    /* optimization.cc:58-68: sinusoid control guess */
+    for (int t = 0; t < 4; ++t) guess[t] = state[t];
+    for (int k = 0; k < N; ++k)
+      guess[4 * S + k] =
+          p->u_guess_sinusoid_amplitude * sin((double)k / (double)N * 2 * M_PI);
+  }
+  /* FillInitialGuess, optimization.cc:333-351: roll the states, wrapping after EVERY step */
+  {
+    double x[4] = {guess[0], guess[1], guess[2], guess[3]};
+    for (int s = 1; s < S; ++s) {
+      for (int k = 0; k < sp; ++k) {
+        double xn[4];
+        orc_rk4_no_jacobians(dyn, x, guess[4 * S + (s - 1) * sp + k], p->control_dt, kZero2,
+                             kZero2, xn);
+        memcpy(x, xn, sizeof xn);
+        x[1] = orc_mod_pi(x[1]);
+      }
+      for (int t = 0; t < 4; ++t) guess[4 * s + t] = x[t];
+    }
+  }
+  if (guess_out) memcpy(guess_out, guess, sizeof(double) * (size_t)dim);
+
+  double* z = (double*)malloc(sizeof(double) * (size_t)dim);
+  orc_solve(p, &opt->opts, dyn, state, set_point, u_prev, guess, z, summary);
+
+  /* optimization.cc:85 */
+  memcpy(opt->prev, z, sizeof(double) * (size_t)dim);
+  opt->has_prev = 1;
+
+  if (u_out)
+    for (int k = 0; k < N; ++k) u_out[k] = z[4 * S + k]; /* optimization.cc:88-89 */
+
+  /* ComputePredictedStates, optimization.cc:353-371 */
+  if (predicted_out) {
+    double x[4] = {state[0], state[1], state[2], state[3]};
+    for (int k = 0; k < N; ++k) {
+      double xn[4];
+      orc_rk4_no_jacobians(dyn, x, z[4 * S + k], p->control_dt, kZero2, kZero2, xn);
+      memcpy(x, xn, sizeof xn);
+      x[1] = orc_mod_pi(x[1]);
+      for (int t = 0; t < 4; ++t) predicted_out[4 * k + t] = x[t];
+    }
+  }
+  if (z_out) memcpy(z_out, z, sizeof(double) * (size_t)dim);
+  free(z);
+  free(guess);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* Simulator                                                                                    */
+/* ------------------------------------------------------------------------------------------- */
+
+/* optimization/simulator.cc:11-36: fixed 1 ms sub-steps, angle wrapped after each */
+void orc_sim_step(const double params[9], double dt, double u, const double f_base[2],
+                  const double f_mass[2], double state[4]) {
+  const double internal_dt = 0.001;
+  while (dt > 0.0) {
+    const double h = dt < internal_dt ? dt : internal_dt;
+    double xn[4];
+    orc_rk4_no_jacobians(params, state, u, h, f_base, f_mass, xn);
+    memcpy(state, xn, sizeof xn);
+    state[1] = orc_mod_pi(state[1]);
+    dt -= internal_dt;
+  }
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* batch driver                                                                                 */
+/* ------------------------------------------------------------------------------------------- */
+
+int orc_step_batch_cold(const orc_opt_params* p, const orc_solver_opts* o, const double dyn[9],
+                        double set_point, int64_t B, const double* x0_soa, double* u_out_soa,
+                        double* pred_out_soa, int32_t* status, int32_t* iters, int num_threads) {
+  const int N = (int)p->window_length;
+  int used = 1;
+#ifdef _OPENMP
+  if (num_threads > 0) omp_set_num_threads(num_threads);
+  used = omp_get_max_threads();
+#else
+  (void)num_threads;
+#endif
+#pragma omp parallel
+  {
+    orc_optimization* opt = orc_opt_create(p, o);
+    double* u = (double*)malloc(sizeof(double) * (size_t)N);
+    double* pred = (double*)malloc(sizeof(double) * 4 * (size_t)N);
+#pragma omp for schedule(dynamic, 16)
+    for (int64_t b = 0; b < B; ++b) {
+      if (!opt) continue;
+      orc_opt_reset(opt);
+      const double x0[4] = {x0_soa[0 * B + b], x0_soa[1 * B + b], x0_soa[2 * B + b],
+                            x0_soa[3 * B + b]};
+      orc_solver_summary sum;
+      orc_opt_step(opt, x0, dyn, set_point, u, pred_out_soa ? pred : NULL, NULL, NULL, &sum);
+      for (int k = 0; k < N; ++k) u_out_soa[(int64_t)k * B + b] = u[k];
+      if (pred_out_soa)
+        for (int k = 0; k < N; ++k)
+          for (int t = 0; t < 4; ++t) pred_out_soa[((int64_t)k * 4 + t) * B + b] = pred[4 * k + t];
+      if (status) status[b] = sum.termination_state;
+      if (iters) iters[b] = sum.iterations;
+    }
+    free(u);
+    free(pred);
+    orc_opt_destroy(opt);
+  }
+  return used;
+}
