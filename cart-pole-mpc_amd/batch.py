@@ -1,0 +1,283 @@
+"""Batched host API over the C-ABI: torch tensors (device memory + streams only) in, tensors out.
+
+Names follow the reference's interface for this path (optimization/optimization.hpp:73-108,
+optimization/simulator.hpp:10-29): Optimization -> BatchOptimization with step / reset /
+set_previous_solution; Simulator -> BatchSimulator with step / get_state / set_state.
+Every array is structure-of-arrays, [field, B].  All compute happens in libcpmpc.so's HIP kernels;
+this module raises if the library or a gfx950 device is missing.
+"""
+import ctypes as C
+
+import torch
+
+from . import capi
+
+_TORCH_DTYPE = {capi.F32: torch.float32, capi.F64: torch.float64}
+_CAPI_DTYPE = {torch.float32: capi.F32, torch.float64: capi.F64}
+
+
+def _stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_cuda_tensor(t, name, dtype, shape=None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TypeError("%s must be a GPU tensor" % name)
+    if t.dtype != dtype:
+        raise TypeError("%s must have dtype %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous ([field, B], batch fastest)" % name)
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError("%s must have shape %s, got %s" % (name, tuple(shape), tuple(t.shape)))
+    return t
+
+
+def _ptr(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+class BatchOutputs:
+    """Batched OptimizationOutputs (optimization/optimization.hpp:55-70)."""
+
+    def __init__(self):
+        self.u = None                 # [N, B]
+        self.predicted_states = None  # [N, 4, B]
+        self.status = None            # [B] int32, termination state
+        self.iterations = None        # [B] int32
+        self.ls_evals = None          # [B] int32
+        self.final_cost = None        # [B]
+        self.final_eq_l1 = None       # [B]
+        self.guess = None             # [dim, B]
+
+    def solver_summary(self):
+        """Batch summary in the spirit of NLSSolverOutputs::ToString (wrapper/wrapper.cc:82-83)."""
+        st = self.status.cpu()
+        lines = ["batch of %d problems" % st.numel()]
+        for code in sorted(set(st.tolist())):
+            lines.append("  %-28s %d" % (capi.TERM_NAMES.get(code, str(code)), int((st == code).sum())))
+        if self.iterations is not None:
+            it = self.iterations.cpu().float()
+            lines.append("  iterations: mean %.2f max %d" % (it.mean().item(), int(it.max().item())))
+        if self.final_eq_l1 is not None:
+            lines.append("  max |c|_1: %.3e" % self.final_eq_l1.abs().max().item())
+        return "\n".join(lines)
+
+
+class BatchOptimization:
+    """B independent pendulum::Optimization controllers solved in lock-step on one GPU."""
+
+    def __init__(self, params, max_batch, dtype=torch.float32, device=None, opts=None):
+        lib = capi.load()
+        if dtype not in _CAPI_DTYPE:
+            raise TypeError("dtype must be torch.float32 or torch.float64")
+        if device is None:
+            device = torch.cuda.current_device()
+        self.params = params
+        self.opts = opts
+        self.dtype = dtype
+        self.device = int(device)
+        self.max_batch = int(max_batch)
+        self._h = C.c_void_p()
+        capi.check(lib.cpmpc_create(C.byref(params), C.byref(opts) if opts is not None else None,
+                                    _CAPI_DTYPE[dtype], self.max_batch, self.device,
+                                    C.byref(self._h)))
+        self.N = int(params.window_length)
+        self.S = lib.cpmpc_num_states(self._h)
+        self.dim = lib.cpmpc_dim(self._h)
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            capi.load().cpmpc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- Optimization::Step -------------------------------------------------------------------
+    def step(self, x0, dyn, set_point=0.0, want_predicted=True, want_stats=True, want_guess=False,
+             out=None):
+        """x0: [4, B] tensor.  dyn: 9 floats (shared) or a [9, B] tensor.  set_point: float or [B]."""
+        lib = capi.load()
+        dev = torch.device("cuda", self.device)
+        _require_cuda_tensor(x0, "x0", self.dtype)
+        if x0.dim() != 2 or x0.shape[0] != 4:
+            raise ValueError("x0 must be [4, B]")
+        B = int(x0.shape[1])
+        inp = capi.StepInputs()
+        inp.x0 = x0.data_ptr()
+        keep = [x0]
+        if isinstance(dyn, torch.Tensor):
+            _require_cuda_tensor(dyn, "dyn", self.dtype, (9, B))
+            inp.dyn = dyn.data_ptr()
+            inp.dyn_shared_host = None
+            keep.append(dyn)
+        else:
+            arr = capi.dbl_array(dyn, 9)
+            inp.dyn_shared_host = C.cast(arr, C.POINTER(C.c_double))
+            inp.dyn = None
+            keep.append(arr)
+        if isinstance(set_point, torch.Tensor):
+            _require_cuda_tensor(set_point, "set_point", self.dtype, (B,))
+            inp.set_point = set_point.data_ptr()
+            inp.set_point_shared = 0.0
+            keep.append(set_point)
+        else:
+            inp.set_point = None
+            inp.set_point_shared = float(set_point)
+
+        o = out if out is not None else BatchOutputs()
+        if o.u is None or tuple(o.u.shape) != (self.N, B):
+            o.u = torch.empty((self.N, B), dtype=self.dtype, device=dev)
+        if want_predicted and (o.predicted_states is None
+                               or tuple(o.predicted_states.shape) != (self.N, 4, B)):
+            o.predicted_states = torch.empty((self.N, 4, B), dtype=self.dtype, device=dev)
+        if o.status is None or o.status.numel() != B:
+            o.status = torch.empty((B,), dtype=torch.int32, device=dev)
+        if want_stats and (o.iterations is None or o.iterations.numel() != B):
+            o.iterations = torch.empty((B,), dtype=torch.int32, device=dev)
+            o.ls_evals = torch.empty((B,), dtype=torch.int32, device=dev)
+            o.final_cost = torch.empty((B,), dtype=self.dtype, device=dev)
+            o.final_eq_l1 = torch.empty((B,), dtype=self.dtype, device=dev)
+        if want_guess:
+            o.guess = torch.empty((self.dim, B), dtype=self.dtype, device=dev)
+        outp = capi.StepOutputs()
+        outp.u = o.u.data_ptr()
+        outp.predicted = o.predicted_states.data_ptr() if want_predicted else None
+        outp.status = o.status.data_ptr()
+        if want_stats:
+            outp.iterations = o.iterations.data_ptr()
+            outp.ls_evals = o.ls_evals.data_ptr()
+            outp.final_cost = o.final_cost.data_ptr()
+            outp.final_eq_l1 = o.final_eq_l1.data_ptr()
+        outp.guess = o.guess.data_ptr() if want_guess else None
+        with torch.cuda.device(self.device):
+            capi.check(lib.cpmpc_step_batch(self._h, B, C.byref(inp), C.byref(outp), _stream_ptr()))
+        self._keep = keep  # inputs must outlive the asynchronous launch
+        return o
+
+    # -- Optimization::Reset / SetPreviousSolution ---------------------------------------------
+    def reset(self):
+        capi.check(capi.load().cpmpc_reset(self._h))
+
+    def has_previous_solution(self):
+        return bool(capi.load().cpmpc_has_previous_solution(self._h))
+
+    def set_previous_solution(self, z):
+        _require_cuda_tensor(z, "z", self.dtype)
+        if z.dim() != 2 or z.shape[0] != self.dim:
+            raise ValueError("z must be [dim=%d, B]" % self.dim)
+        with torch.cuda.device(self.device):
+            capi.check(capi.load().cpmpc_set_previous_solution(self._h, int(z.shape[1]), _ptr(z),
+                                                               _stream_ptr()))
+
+    def get_solution(self, B):
+        z = torch.empty((self.dim, int(B)), dtype=self.dtype, device=torch.device("cuda", self.device))
+        with torch.cuda.device(self.device):
+            capi.check(capi.load().cpmpc_get_solution(self._h, int(B), _ptr(z), _stream_ptr()))
+        return z
+
+    # -- pieces -------------------------------------------------------------------------------
+    def linearize(self, z, dyn):
+        """Shooting constraints linearised at z [dim, B] -> (c [4(S-1), B], Phi [S-1,4,4,B],
+        Gamma [N,4,B] with Gamma[k, r] = d x_end[r] / d u_k)."""
+        _require_cuda_tensor(z, "z", self.dtype)
+        B = int(z.shape[1])
+        dev = z.device
+        c = torch.empty((4 * (self.S - 1), B), dtype=self.dtype, device=dev)
+        Phi = torch.empty((self.S - 1, 4, 4, B), dtype=self.dtype, device=dev)
+        Gam = torch.empty((self.N, 4, B), dtype=self.dtype, device=dev)
+        arr = capi.dbl_array(dyn, 9)
+        with torch.cuda.device(self.device):
+            capi.check(capi.load().cpmpc_linearize_batch(self._h, B, arr, _ptr(z), _ptr(c), _ptr(Phi),
+                                                         _ptr(Gam), _stream_ptr()))
+        return c, Phi, Gam
+
+    # -- measurement --------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        capi.check(capi.load().cpmpc_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self):
+        capi.check(capi.load().cpmpc_profile_reset(self._h))
+
+    def profile_read(self):
+        """{kernel name: (total_ms, launches)} accumulated since the last reset."""
+        lib = capi.load()
+        res = {}
+        for kid in range(capi.KERNEL_COUNT):
+            ms, n = C.c_double(), C.c_int64()
+            capi.check(lib.cpmpc_profile_read(self._h, kid, C.byref(ms), C.byref(n)))
+            res[lib.cpmpc_kernel_name(kid).decode()] = (ms.value, n.value)
+        return res
+
+
+def _fext(fext):
+    return None if fext is None else capi.dbl_array(fext, 4)
+
+
+def dynamics_batch(dyn, x, u, fext=None, jacobians=True):
+    """gen::single_pendulum_dynamics batched: x [4,B], u [B] -> f [4,B] (+ Jx [4,4,B], Ju [4,B])."""
+    dt = x.dtype
+    _require_cuda_tensor(x, "x", dt)
+    B = int(x.shape[1])
+    _require_cuda_tensor(u, "u", dt, (B,))
+    f = torch.empty_like(x)
+    Jx = torch.empty((4, 4, B), dtype=dt, device=x.device) if jacobians else None
+    Ju = torch.empty((4, B), dtype=dt, device=x.device) if jacobians else None
+    with torch.cuda.device(x.device):
+        capi.check(capi.load().cpmpc_dynamics_batch(_CAPI_DTYPE[dt], B, capi.dbl_array(dyn, 9), _ptr(x),
+                                                    _ptr(u), _fext(fext), _ptr(f), _ptr(Jx), _ptr(Ju),
+                                                    _stream_ptr()))
+    return (f, Jx, Ju) if jacobians else f
+
+
+def rk4_batch(dyn, x, u, h, fext=None, jacobians=True):
+    """runge_kutta_4th_order<4> (or _no_jacobians) batched: -> x_new [4,B] (+ A [4,4,B], B [4,B])."""
+    dt = x.dtype
+    _require_cuda_tensor(x, "x", dt)
+    B = int(x.shape[1])
+    _require_cuda_tensor(u, "u", dt, (B,))
+    xn = torch.empty_like(x)
+    A = torch.empty((4, 4, B), dtype=dt, device=x.device) if jacobians else None
+    Bm = torch.empty((4, B), dtype=dt, device=x.device) if jacobians else None
+    with torch.cuda.device(x.device):
+        capi.check(capi.load().cpmpc_rk4_batch(_CAPI_DTYPE[dt], B, capi.dbl_array(dyn, 9), _ptr(x), _ptr(u),
+                                               float(h), _fext(fext), _ptr(xn), _ptr(A), _ptr(Bm),
+                                               _stream_ptr()))
+    return (xn, A, Bm) if jacobians else xn
+
+
+class BatchSimulator:
+    """B independent pendulum::Simulator plants (optimization/simulator.hpp:10-29)."""
+
+    def __init__(self, batch, dtype=torch.float32, device=None):
+        capi.load()
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = torch.device("cuda", int(device))
+        self.dtype = dtype
+        init = torch.tensor([0.0, -3.14159265358979323846 / 2, 0.0, 0.0], dtype=dtype)  # simulator.hpp:28
+        self.state = init.to(self.device).reshape(4, 1).repeat(1, int(batch)).contiguous()
+
+    def get_state(self):
+        return self.state
+
+    def set_state(self, state):
+        _require_cuda_tensor(state, "state", self.dtype, tuple(self.state.shape))
+        self.state = state.clone()
+
+    def step(self, params, dt, u, f_base=(0.0, 0.0), f_mass=(0.0, 0.0), fext=None):
+        """u: [B] tensor.  f_base/f_mass shared (x, y) pairs, or fext a [4, B] tensor
+        {f_base.x, f_base.y, f_mass.x, f_mass.y}."""
+        B = int(self.state.shape[1])
+        _require_cuda_tensor(u, "u", self.dtype, (B,))
+        shared = capi.dbl_array([f_base[0], f_base[1], f_mass[0], f_mass[1]], 4)
+        if fext is not None:
+            _require_cuda_tensor(fext, "fext", self.dtype, (4, B))
+        with torch.cuda.device(self.device):
+            capi.check(capi.load().cpmpc_sim_step_batch(_CAPI_DTYPE[self.dtype], B, capi.dbl_array(params, 9),
+                                                        float(dt), _ptr(u), shared, _ptr(fext),
+                                                        _ptr(self.state), _stream_ptr()))

@@ -1,0 +1,348 @@
+// cartpole_device.hpp -- gfx950 device functions: cart-pole dynamics with analytic Jacobians and
+// the RK4 step with/without sensitivities.  One problem per lane, everything in registers.
+//
+// Behaviour follows (reference paths relative to /root/reference):
+//   gen::single_pendulum_dynamics        optimization/single_pendulum_dynamics.hpp:13-186
+//     (written from the Lagrangian spec symbolic/dynamics_single.py:58-143)
+//   runge_kutta_4th_order<D>             optimization/integration.hpp:13-49
+//   runge_kutta_4th_order_no_jacobians   optimization/integration.hpp:52-62
+//   mod_pi                               optimization/integration.hpp:65-73
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace cpmpc {
+
+// ------------------------------------------------------------------------------------------------
+// scalar math per dtype
+// ------------------------------------------------------------------------------------------------
+template <typename R>
+struct Math;
+
+template <>
+struct Math<float> {
+  static __device__ __forceinline__ void sincos(float x, float& s, float& c) { ::sincosf(x, &s, &c); }
+  static __device__ __forceinline__ float tanh(float x) { return ::tanhf(x); }
+  static __device__ __forceinline__ float sqrt(float x) { return ::sqrtf(x); }
+  static __device__ __forceinline__ float fabs(float x) { return ::fabsf(x); }
+  static __device__ __forceinline__ float fmod(float x, float y) { return ::fmodf(x, y); }
+  static __device__ __forceinline__ bool finite(float x) { return ::isfinite(x); }
+};
+
+template <>
+struct Math<double> {
+  static __device__ __forceinline__ void sincos(double x, double& s, double& c) { ::sincos(x, &s, &c); }
+  static __device__ __forceinline__ double tanh(double x) { return ::tanh(x); }
+  static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
+  static __device__ __forceinline__ double fabs(double x) { return ::fabs(x); }
+  static __device__ __forceinline__ double fmod(double x, double y) { return ::fmod(x, y); }
+  static __device__ __forceinline__ bool finite(double x) { return ::isfinite(x); }
+};
+
+// Map an angle to (-pi, pi]; same cut as integration.hpp:65-73 (mod_pi(+-pi) = +pi).
+template <typename R>
+__device__ __forceinline__ R mod_pi(R angle) {
+  constexpr R pi = static_cast<R>(3.14159265358979323846);
+  constexpr R two_pi = 2 * pi;
+  angle = Math<R>::fmod(angle, two_pi);
+  angle += (angle < R(0)) ? two_pi : R(0);
+  angle -= (angle > pi) ? two_pi : R(0);
+  return angle;
+}
+
+// ------------------------------------------------------------------------------------------------
+// model constants: SingleCartPoleParams (structs.hpp:8-41) plus the sub-expressions that depend on
+// the parameters only, hoisted out of the per-stage evaluation.
+// ------------------------------------------------------------------------------------------------
+template <typename R>
+struct CartPoleConsts {
+  R m_1, L, g, xs, ks;
+  R mt;         // m_1 + m_b
+  R inv_v_mu;   // 1 / max(v_mu_b, 1e-6)
+  R fr;         // -(mt * mu_b) * g      friction scale
+  R inv_L;      // 1 / L
+  R kap;        // mt / (m_1 L^2)
+  R m1L;        // m_1 * L
+  R gm1L;       // g * m_1 * L
+  R half_cd;    // c_d / 2
+  R half_cd_L;  // c_d L / 2
+};
+
+template <typename R, typename P>
+__host__ __device__ inline CartPoleConsts<R> make_consts(const P* p) {
+  // p = {m_b, m_1, l_1, g, mu_b, v_mu_b, c_d_1, x_s, k_s}; evaluated in P, rounded once to R.
+  const P m_b = p[0], m_1 = p[1], L = p[2], g = p[3], mu = p[4], v_mu_in = p[5], cd = p[6];
+  const P mt = m_1 + m_b;
+  const P v_mu = (P(1.0e-6) < v_mu_in) ? v_mu_in : P(1.0e-6);
+  CartPoleConsts<R> k;
+  k.m_1 = R(m_1);
+  k.L = R(L);
+  k.g = R(g);
+  k.xs = R(p[7]);
+  k.ks = R(p[8]);
+  k.mt = R(mt);
+  k.inv_v_mu = R(P(1) / v_mu);
+  k.fr = R((mt * mu) * -g);
+  k.inv_L = R(P(1) / L);
+  k.kap = R(mt / (m_1 * L * L));
+  k.m1L = R(m_1 * L);
+  k.gm1L = R(g * m_1 * L);
+  k.half_cd = R(P(0.5) * cd);
+  k.half_cd_L = R(P(0.5) * cd * L);
+  return k;
+}
+
+// External forces {f_base.x, f_mass.x, f_mass.y}; f_base.y never enters the equations.
+template <typename R>
+struct ExtForce {
+  R fbx, fmx, fmy;
+};
+
+// ------------------------------------------------------------------------------------------------
+// accelerations (b_x'', th_1'') and, optionally, their partials.
+//   Ja[r][c] : d(acc_r)/d(b_x, th, b_x', th')      Jua[r] : d(acc_r)/du
+// The full 4x4 stage Jacobian is [[0 0 1 0],[0 0 0 1],[Ja]] (single_pendulum_dynamics.hpp:159-166);
+// only the two non-trivial rows are ever materialised.
+// ------------------------------------------------------------------------------------------------
+template <typename R, bool WITH_J, bool HAS_EXT>
+__device__ __forceinline__ void cartpole_accel(const CartPoleConsts<R>& k, const R bx, const R th,
+                                               const R v, const R w, const R u,
+                                               const ExtForce<R>& fe, R& a_x, R& a_th,
+                                               R (&Ja)[2][4], R (&Jua)[2]) {
+  R s, c;
+  Math<R>::sincos(th, s, c);
+
+  // bumper springs (strict comparisons, as the generated branches)
+  const R e_r = bx - k.xs;
+  const R e_l = -(bx + k.xs);
+  const bool on_r = R(0) < e_r;
+  const bool on_l = R(0) < e_l;
+  const R F_s = k.ks * ((on_l ? e_l : R(0)) - (on_r ? e_r : R(0)));
+
+  // smoothed Coulomb friction
+  const R tv = Math<R>::tanh(v * k.inv_v_mu);
+  const R F_f = tv * k.fr;
+
+  // air drag on the pole mass
+  const R Lw = k.L * w;
+  const R vx = v - Lw * s;
+  const R vy = Lw * c;
+  const R n2 = vx * vx + vy * vy;
+  const R n = Math<R>::sqrt(n2);
+  const bool on_d = R(0) < n2;
+  const R e = Lw - s * v;  // = c*vy - s*vx
+  const R Dx = on_d ? k.half_cd * n * vx : R(0);
+  const R Dth = on_d ? k.half_cd_L * n * e : R(0);
+
+  R F_b = u + F_f + F_s - Dx + k.m1L * w * w * c;
+  R F_th = -k.gm1L * c - Dth;
+  if (HAS_EXT) {
+    F_b += fe.fbx + fe.fmx;
+    F_th += k.L * (fe.fmy * c - fe.fmx * s);
+  }
+
+  const R den = k.mt - k.m_1 * s * s;
+  const R inv_den = R(1) / den;
+  const R sl = s * k.inv_L;
+  const R N_x = F_b + sl * F_th;
+  const R N_th = sl * F_b + k.kap * F_th;
+  a_x = N_x * inv_den;
+  a_th = N_th * inv_den;
+
+  if (WITH_J) {
+    // partials of the drag terms with respect to (th, v, w)
+    R dDx0 = R(0), dDx1 = R(0), dDx2 = R(0), dDt0 = R(0), dDt1 = R(0), dDt2 = R(0);
+    if (on_d) {
+      const R inv_n = R(1) / n;
+      // d|v|/d(th, v, w)
+      const R dn0 = (vx * (-Lw * c) + vy * (-Lw * s)) * inv_n;
+      const R dn1 = vx * inv_n;
+      const R dn2 = (vx * (-k.L * s) + vy * (k.L * c)) * inv_n;
+      dDx0 = k.half_cd * (dn0 * vx + n * (-Lw * c));
+      dDx1 = k.half_cd * (dn1 * vx + n);
+      dDx2 = k.half_cd * (dn2 * vx + n * (-k.L * s));
+      dDt0 = k.half_cd_L * (dn0 * e + n * (-c * v));
+      dDt1 = k.half_cd_L * (dn1 * e + n * (-s));
+      dDt2 = k.half_cd_L * (dn2 * e + n * k.L);
+    }
+    const R dFf_dv = k.inv_v_mu * (R(1) - tv * tv) * k.fr;
+    const R dFs_dbx = k.ks * ((on_l ? R(-1) : R(0)) - (on_r ? R(1) : R(0)));
+
+    const R dFb0 = -dDx0 - k.m1L * w * w * s;
+    const R dFb1 = dFf_dv - dDx1;
+    const R dFb2 = -dDx2 + R(2) * k.m1L * w * c;
+    R dFt0 = k.gm1L * s - dDt0;
+    if (HAS_EXT) dFt0 += k.L * (-fe.fmx * c - fe.fmy * s);
+    const R dFt1 = -dDt1;
+    const R dFt2 = -dDt2;
+
+    const R dden = R(-2) * k.m_1 * s * c;
+    const R cl = c * k.inv_L;
+    const R dNx0 = dFb0 + cl * F_th + sl * dFt0;
+    const R dNx1 = dFb1 + sl * dFt1;
+    const R dNx2 = dFb2 + sl * dFt2;
+    const R dNt0 = cl * F_b + sl * dFb0 + k.kap * dFt0;
+    const R dNt1 = sl * dFb1 + k.kap * dFt1;
+    const R dNt2 = sl * dFb2 + k.kap * dFt2;
+
+    Ja[0][0] = dFs_dbx * inv_den;
+    Ja[0][1] = (dNx0 - a_x * dden) * inv_den;
+    Ja[0][2] = dNx1 * inv_den;
+    Ja[0][3] = dNx2 * inv_den;
+    Ja[1][0] = sl * dFs_dbx * inv_den;
+    Ja[1][1] = (dNt0 - a_th * dden) * inv_den;
+    Ja[1][2] = dNt1 * inv_den;
+    Ja[1][3] = dNt2 * inv_den;
+    Jua[0] = inv_den;       // single_pendulum_dynamics.hpp:179-184
+    Jua[1] = sl * inv_den;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// RK4 without sensitivities (integration.hpp:52-62).  x updated in place.
+// ------------------------------------------------------------------------------------------------
+template <typename R, bool HAS_EXT>
+__device__ __forceinline__ void rk4_step(const CartPoleConsts<R>& k, const R h, R (&x)[4],
+                                         const R u, const ExtForce<R>& fe) {
+  R Ja[2][4], Jua[2];
+  const R hh = h / R(2);
+  R a1x, a1t, a2x, a2t, a3x, a3t, a4x, a4t;
+  // k1 = f(x)
+  cartpole_accel<R, false, HAS_EXT>(k, x[0], x[1], x[2], x[3], u, fe, a1x, a1t, Ja, Jua);
+  const R k1_0 = x[2], k1_1 = x[3];
+  // k2 = f(x + k1 h/2)
+  const R k2_0 = x[2] + a1x * hh, k2_1 = x[3] + a1t * hh;
+  cartpole_accel<R, false, HAS_EXT>(k, x[0] + k1_0 * hh, x[1] + k1_1 * hh, k2_0, k2_1, u, fe, a2x,
+                                    a2t, Ja, Jua);
+  // k3 = f(x + k2 h/2)
+  const R k3_0 = x[2] + a2x * hh, k3_1 = x[3] + a2t * hh;
+  cartpole_accel<R, false, HAS_EXT>(k, x[0] + k2_0 * hh, x[1] + k2_1 * hh, k3_0, k3_1, u, fe, a3x,
+                                    a3t, Ja, Jua);
+  // k4 = f(x + k3 h)
+  const R k4_0 = x[2] + a3x * h, k4_1 = x[3] + a3t * h;
+  cartpole_accel<R, false, HAS_EXT>(k, x[0] + k3_0 * h, x[1] + k3_1 * h, k4_0, k4_1, u, fe, a4x,
+                                    a4t, Ja, Jua);
+  const R h6 = h / R(6);
+  x[0] += h6 * (k1_0 + k2_0 * R(2) + k3_0 * R(2) + k4_0);
+  x[1] += h6 * (k1_1 + k2_1 * R(2) + k3_1 * R(2) + k4_1);
+  x[2] += h6 * (a1x + a2x * R(2) + a3x * R(2) + a4x);
+  x[3] += h6 * (a1t + a2t * R(2) + a3t * R(2) + a4t);
+}
+
+// ------------------------------------------------------------------------------------------------
+// RK4 with sensitivities A = dx+/dx (4x4), Bv = dx+/du (4)   (integration.hpp:13-49).
+//
+// Stage chain rule with K_j = [[0 I],[Ja_j]] the stage Jacobian at the stage argument:
+//   D_1 = K_1,  D_{j+1} = K_{j+1} (I + a_j D_j),  a = {h/2, h/2, h}
+//   A = I + h/6 (D_1 + 2 D_2 + 2 D_3 + D_4)
+// The top two rows of K X are rows 2,3 of X and the bottom two are Ja X, so each stage product
+// costs 2x4x4 multiply-adds instead of 4x4x4.  Same for the control column d_j.
+// ------------------------------------------------------------------------------------------------
+template <typename R>
+__device__ __forceinline__ void stage_chain(const R (&Ja)[2][4], const R (&Jua)[2], const R a,
+                                            const R (&D)[4][4], const R (&d)[4], R (&Dn)[4][4],
+                                            R (&dn)[4]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    Dn[0][c] = a * D[2][c] + (c == 2 ? R(1) : R(0));
+    Dn[1][c] = a * D[3][c] + (c == 3 ? R(1) : R(0));
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const R acc = Ja[r][0] * D[0][c] + Ja[r][1] * D[1][c] + Ja[r][2] * D[2][c] + Ja[r][3] * D[3][c];
+      Dn[2 + r][c] = Ja[r][c] + a * acc;
+    }
+  }
+  dn[0] = a * d[2];
+  dn[1] = a * d[3];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const R acc = Ja[r][0] * d[0] + Ja[r][1] * d[1] + Ja[r][2] * d[2] + Ja[r][3] * d[3];
+    dn[2 + r] = a * acc + Jua[r];
+  }
+}
+
+template <typename R, bool HAS_EXT>
+__device__ __forceinline__ void rk4_step_jac(const CartPoleConsts<R>& k, const R h, R (&x)[4],
+                                             const R u, const ExtForce<R>& fe, R (&A)[4][4],
+                                             R (&Bv)[4]) {
+  const R hh = h / R(2);
+  R Ja[2][4], Jua[2];
+  R D[4][4], d[4], Dn[4][4], dn[4];
+  R As[4][4], bs[4];  // running sums D_1 + 2 D_2 + 2 D_3 + D_4
+
+  // stage 1
+  R a1x, a1t;
+  cartpole_accel<R, true, HAS_EXT>(k, x[0], x[1], x[2], x[3], u, fe, a1x, a1t, Ja, Jua);
+  const R k1_0 = x[2], k1_1 = x[3];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    D[0][c] = (c == 2 ? R(1) : R(0));
+    D[1][c] = (c == 3 ? R(1) : R(0));
+    D[2][c] = Ja[0][c];
+    D[3][c] = Ja[1][c];
+  }
+  d[0] = R(0);
+  d[1] = R(0);
+  d[2] = Jua[0];
+  d[3] = Jua[1];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) As[r][c] = D[r][c];
+    bs[r] = d[r];
+  }
+
+  // stage 2
+  R a2x, a2t;
+  const R k2_0 = x[2] + a1x * hh, k2_1 = x[3] + a1t * hh;
+  cartpole_accel<R, true, HAS_EXT>(k, x[0] + k1_0 * hh, x[1] + k1_1 * hh, k2_0, k2_1, u, fe, a2x,
+                                   a2t, Ja, Jua);
+  stage_chain<R>(Ja, Jua, hh, D, d, Dn, dn);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      As[r][c] += Dn[r][c] * R(2);
+      D[r][c] = Dn[r][c];
+    }
+    bs[r] += dn[r] * R(2);
+    d[r] = dn[r];
+  }
+
+  // stage 3
+  R a3x, a3t;
+  const R k3_0 = x[2] + a2x * hh, k3_1 = x[3] + a2t * hh;
+  cartpole_accel<R, true, HAS_EXT>(k, x[0] + k2_0 * hh, x[1] + k2_1 * hh, k3_0, k3_1, u, fe, a3x,
+                                   a3t, Ja, Jua);
+  stage_chain<R>(Ja, Jua, hh, D, d, Dn, dn);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      As[r][c] += Dn[r][c] * R(2);
+      D[r][c] = Dn[r][c];
+    }
+    bs[r] += dn[r] * R(2);
+    d[r] = dn[r];
+  }
+
+  // stage 4
+  R a4x, a4t;
+  const R k4_0 = x[2] + a3x * h, k4_1 = x[3] + a3t * h;
+  cartpole_accel<R, true, HAS_EXT>(k, x[0] + k3_0 * h, x[1] + k3_1 * h, k4_0, k4_1, u, fe, a4x, a4t,
+                                   Ja, Jua);
+  stage_chain<R>(Ja, Jua, h, D, d, Dn, dn);
+
+  const R h6 = h / R(6);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) A[r][c] = (r == c ? R(1) : R(0)) + h6 * (As[r][c] + Dn[r][c]);
+    Bv[r] = h6 * (bs[r] + dn[r]);
+  }
+  x[0] += h6 * (k1_0 + k2_0 * R(2) + k3_0 * R(2) + k4_0);
+  x[1] += h6 * (k1_1 + k2_1 * R(2) + k3_1 * R(2) + k4_1);
+  x[2] += h6 * (a1x + a2x * R(2) + a3x * R(2) + a4x);
+  x[3] += h6 * (a1t + a2t * R(2) + a3t * R(2) + a4t);
+}
+
+}  // namespace cpmpc

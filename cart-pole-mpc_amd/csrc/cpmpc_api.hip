@@ -1,0 +1,775 @@
+// cpmpc_api.hip -- C-ABI (include/cpmpc.h) over the gfx950 kernels in mpc_kernels.hpp.
+//
+// Host side of the batched cart-pole MPC hot path.  There is no CPU compute path in this library:
+// every entry point that computes launches HIP kernels and fails with CPMPC_ERR_NO_DEVICE when no
+// gfx950 device is usable.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/cpmpc.h"
+#include "mpc_kernels.hpp"
+
+using namespace cpmpc;
+
+// ------------------------------------------------------------------------------------------------
+// error text
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return fail(CPMPC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),     \
+                  __FILE__, __LINE__);                                                      \
+  } while (0)
+
+extern "C" const char* cpmpc_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------------------
+// defaults
+// ------------------------------------------------------------------------------------------------
+extern "C" void cpmpc_default_params(cpmpc_params* p) {  // optimization/optimization.hpp:12-48
+  p->control_dt = 0.01;
+  p->window_length = 40;
+  p->state_spacing = 10;
+  p->max_iterations = 8;
+  p->relative_exit_tol = 1.0e-5;
+  p->absolute_first_derivative_tol = 1.0e-6;
+  p->equality_penalty_initial = 1.0;
+  p->u_guess_sinusoid_amplitude = 10.0;
+  p->u_cost_weight = 0.1;
+  p->u_derivative_cost_weight = 0.1;
+  p->b_x_final_cost_weight = 150.0;
+  p->th_final_cost_weight = -1.0;
+  p->b_x_dot_final_cost_weight = -1.0;
+  p->th_dot_final_cost_weight = -1.0;
+}
+
+extern "C" void cpmpc_default_solver_opts(cpmpc_solver_opts* o) {
+  o->max_line_search_iterations = 5;  // optimization.cc:76
+  o->armijo_c1 = 1.0e-4;
+  o->ls_shrink_max = 0.5;
+  o->ls_shrink_min = 0.1;
+  o->penalty_rho = 0.1;
+  o->lambda_initial = 0.0;
+  o->lambda_failure_init = 1.0e-2;
+  o->lambda_scale_up = 10.0;
+  o->lambda_scale_down = 0.1;
+  o->lambda_min = 1.0e-8;
+  o->lambda_max = 1.0e6;
+  o->b_x_limit = 5.0;  // optimization.cc:320
+  o->u_limit = 300.0;  // optimization.cc:327
+}
+
+// ------------------------------------------------------------------------------------------------
+// device discovery
+// ------------------------------------------------------------------------------------------------
+static bool device_is_gfx950(int dev) {
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+  return strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+}
+
+extern "C" int cpmpc_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  int ok = 0;
+  for (int i = 0; i < n; ++i)
+    if (device_is_gfx950(i)) ++ok;
+  return ok;
+}
+
+static int check_device(int dev) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return fail(CPMPC_ERR_NO_DEVICE,
+                "no HIP device visible; this library has no CPU fallback (libcpmpc needs a gfx950 GPU)");
+  if (dev < 0 || dev >= n) return fail(CPMPC_ERR_NO_DEVICE, "device %d out of range (%d visible)", dev, n);
+  if (!device_is_gfx950(dev))
+    return fail(CPMPC_ERR_NO_DEVICE, "device %d is not gfx950; kernels are built for gfx950 only", dev);
+  return CPMPC_OK;
+}
+
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != dev) {
+      if (hipSetDevice(dev) == hipSuccess) switched = true;
+    }
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// the handle
+// ------------------------------------------------------------------------------------------------
+struct ProfSpan {
+  int kernel;
+  hipEvent_t start, stop;
+};
+
+struct cpmpc_solver {
+  cpmpc_params params;
+  cpmpc_solver_opts opts;
+  int dtype;
+  int device;
+  int64_t cap;  // workspace stride (capacity rounded up to a multiple of 64)
+  int N, S, SP, dim;
+  size_t esize;
+  // one allocation, carved into fields
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+  char *z, *dz, *Phi, *Gam, *cs, *vv, *uu, *dd, *sc;
+  int32_t* ist;
+  void* sin_table = nullptr;
+  int has_prev = 0;
+  // staging for the *_host entry points (lazily allocated)
+  void* stage = nullptr;
+  size_t stage_bytes = 0;
+  // profiling
+  int profiling = 0;
+  std::vector<ProfSpan> spans;
+  std::vector<ProfSpan> free_spans;
+  double prof_ms[CPMPC_KERNEL_COUNT] = {0, 0, 0, 0};
+  int64_t prof_n[CPMPC_KERNEL_COUNT] = {0, 0, 0, 0};
+};
+
+extern "C" int cpmpc_supported_state_spacing(int spacing) {
+  return spacing == 1 || spacing == 2 || spacing == 4 || spacing == 5 || spacing == 8 || spacing == 10 ||
+         spacing == 20;
+}
+
+static int validate_params(const cpmpc_params* p) {
+  // the constructor's preconditions, optimization.cc:13-22
+  if (!(p->control_dt > 0)) return fail(CPMPC_ERR_INVALID_ARG, "control_dt must be > 0 (optimization.cc:14)");
+  if (!(p->window_length >= 1)) return fail(CPMPC_ERR_INVALID_ARG, "window_length must be >= 1 (optimization.cc:15)");
+  if (p->state_spacing == 0 || p->window_length % p->state_spacing != 0)
+    return fail(CPMPC_ERR_INVALID_ARG,
+                "state_spacing (%llu) must divide into window_length (%llu) cleanly (optimization.cc:16-18)",
+                (unsigned long long)p->state_spacing, (unsigned long long)p->window_length);
+  if (!(p->max_iterations >= 1)) return fail(CPMPC_ERR_INVALID_ARG, "max_iterations must be >= 1 (optimization.cc:19)");
+  if (!(p->u_cost_weight >= 0.0)) return fail(CPMPC_ERR_INVALID_ARG, "u_cost_weight must be >= 0 (optimization.cc:20)");
+  if (!(p->u_derivative_cost_weight >= 0.0))
+    return fail(CPMPC_ERR_INVALID_ARG, "u_derivative_cost_weight must be >= 0 (optimization.cc:21)");
+  if (p->window_length > 4096) return fail(CPMPC_ERR_UNSUPPORTED, "window_length > 4096 is not supported");
+  if (!cpmpc_supported_state_spacing((int)p->state_spacing))
+    return fail(CPMPC_ERR_UNSUPPORTED,
+                "state_spacing %llu has no compiled kernel (built: 1,2,4,5,8,10,20)",
+                (unsigned long long)p->state_spacing);
+  return CPMPC_OK;
+}
+
+extern "C" int cpmpc_create(const cpmpc_params* params, const cpmpc_solver_opts* opts, int dtype,
+                            int64_t max_batch, int device, cpmpc_solver** out) {
+  if (!params || !out) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
+  *out = nullptr;
+  if (dtype != CPMPC_F32 && dtype != CPMPC_F64) return fail(CPMPC_ERR_INVALID_ARG, "dtype must be CPMPC_F32 or CPMPC_F64");
+  if (max_batch < 1) return fail(CPMPC_ERR_INVALID_ARG, "max_batch must be >= 1");
+  int rc = validate_params(params);
+  if (rc) return rc;
+  rc = check_device(device);
+  if (rc) return rc;
+  DeviceGuard guard(device);
+
+  cpmpc_solver* s = new (std::nothrow) cpmpc_solver();
+  if (!s) return fail(CPMPC_ERR_ALLOC, "out of host memory");
+  s->params = *params;
+  if (opts)
+    s->opts = *opts;
+  else
+    cpmpc_default_solver_opts(&s->opts);
+  s->dtype = dtype;
+  s->device = device;
+  s->esize = dtype == CPMPC_F32 ? 4 : 8;
+  s->N = (int)params->window_length;
+  s->SP = (int)params->state_spacing;
+  s->S = s->N / s->SP + 1;  // optimization.hpp:52
+  s->dim = 4 * s->S + s->N;
+  s->cap = (max_batch + 63) / 64 * 64;
+
+  const size_t fields_real = (size_t)2 * s->dim + 16 * (s->S - 1) + 4 * s->N + 4 * (s->S - 1) + 3 * s->N + SC_COUNT;
+  const size_t bytes_real = fields_real * (size_t)s->cap * s->esize;
+  const size_t bytes_int = (size_t)IS_COUNT * (size_t)s->cap * sizeof(int32_t);
+  s->ws_bytes = bytes_real + bytes_int;
+  hipError_t e = hipMalloc(&s->ws, s->ws_bytes);
+  if (e != hipSuccess) {
+    delete s;
+    return fail(CPMPC_ERR_ALLOC, "hipMalloc of %zu bytes of workspace failed: %s", bytes_real + bytes_int,
+                hipGetErrorString(e));
+  }
+  (void)hipMemset(s->ws, 0, s->ws_bytes);
+  char* pch = (char*)s->ws;
+  auto carve = [&](size_t nfields) {
+    char* r = pch;
+    pch += nfields * (size_t)s->cap * s->esize;
+    return r;
+  };
+  s->z = carve(s->dim);
+  s->dz = carve(s->dim);
+  s->Phi = carve(16 * (s->S - 1));
+  s->Gam = carve(4 * s->N);
+  s->cs = carve(4 * (s->S - 1));
+  s->vv = carve(s->N);
+  s->uu = carve(s->N);
+  s->dd = carve(s->N);
+  s->sc = carve(SC_COUNT);
+  s->ist = (int32_t*)pch;
+
+  // sinusoid cold-start table, evaluated on the host in double exactly as optimization.cc:63-67
+  std::vector<double> tab(s->N);
+  for (int k = 0; k < s->N; ++k)
+    tab[k] = params->u_guess_sinusoid_amplitude *
+             std::sin(static_cast<double>(k) / static_cast<double>(s->N) * 2 * M_PI);
+  e = hipMalloc(&s->sin_table, (size_t)s->N * s->esize);
+  if (e != hipSuccess) {
+    (void)hipFree(s->ws);
+    delete s;
+    return fail(CPMPC_ERR_ALLOC, "hipMalloc failed: %s", hipGetErrorString(e));
+  }
+  if (dtype == CPMPC_F32) {
+    std::vector<float> tf(tab.begin(), tab.end());
+    e = hipMemcpy(s->sin_table, tf.data(), tf.size() * 4, hipMemcpyHostToDevice);
+  } else {
+    e = hipMemcpy(s->sin_table, tab.data(), tab.size() * 8, hipMemcpyHostToDevice);
+  }
+  if (e != hipSuccess) {
+    (void)hipFree(s->ws);
+    (void)hipFree(s->sin_table);
+    delete s;
+    return fail(CPMPC_ERR_HIP, "hipMemcpy failed: %s", hipGetErrorString(e));
+  }
+  *out = s;
+  return CPMPC_OK;
+}
+
+extern "C" void cpmpc_destroy(cpmpc_solver* s) {
+  if (!s) return;
+  DeviceGuard guard(s->device);
+  for (auto& sp : s->spans) {
+    (void)hipEventDestroy(sp.start);
+    (void)hipEventDestroy(sp.stop);
+  }
+  for (auto& sp : s->free_spans) {
+    (void)hipEventDestroy(sp.start);
+    (void)hipEventDestroy(sp.stop);
+  }
+  if (s->ws) (void)hipFree(s->ws);
+  if (s->sin_table) (void)hipFree(s->sin_table);
+  if (s->stage) (void)hipFree(s->stage);
+  delete s;
+}
+
+extern "C" int cpmpc_dim(const cpmpc_solver* s) { return s ? s->dim : -1; }
+extern "C" int cpmpc_num_states(const cpmpc_solver* s) { return s ? s->S : -1; }
+extern "C" int cpmpc_dtype(const cpmpc_solver* s) { return s ? s->dtype : -1; }
+extern "C" int cpmpc_has_previous_solution(const cpmpc_solver* s) { return s ? s->has_prev : 0; }
+
+extern "C" int cpmpc_reset(cpmpc_solver* s) {  // Optimization::Reset, optimization.hpp:83
+  if (!s) return fail(CPMPC_ERR_INVALID_ARG, "null solver");
+  s->has_prev = 0;
+  return CPMPC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// profiling spans
+// ------------------------------------------------------------------------------------------------
+static const char* kKernelNames[CPMPC_KERNEL_COUNT] = {"prepare_kernel", "linearize_kernel", "qp_ls_kernel",
+                                                       "finalize_kernel"};
+extern "C" const char* cpmpc_kernel_name(int kernel) {
+  return (kernel >= 0 && kernel < CPMPC_KERNEL_COUNT) ? kKernelNames[kernel] : "?";
+}
+
+static void span_begin(cpmpc_solver* s, int kernel, hipStream_t stream, ProfSpan* cur) {
+  if (!s->profiling) return;
+  if (!s->free_spans.empty()) {
+    *cur = s->free_spans.back();
+    s->free_spans.pop_back();
+  } else {
+    (void)hipEventCreate(&cur->start);
+    (void)hipEventCreate(&cur->stop);
+  }
+  cur->kernel = kernel;
+  (void)hipEventRecord(cur->start, stream);
+}
+static void span_end(cpmpc_solver* s, hipStream_t stream, ProfSpan* cur) {
+  if (!s->profiling) return;
+  (void)hipEventRecord(cur->stop, stream);
+  s->spans.push_back(*cur);
+}
+
+static void collect_spans(cpmpc_solver* s) {
+  for (auto& sp : s->spans) {
+    float ms = 0.f;
+    if (hipEventSynchronize(sp.stop) == hipSuccess && hipEventElapsedTime(&ms, sp.start, sp.stop) == hipSuccess) {
+      s->prof_ms[sp.kernel] += ms;
+      s->prof_n[sp.kernel] += 1;
+    }
+    s->free_spans.push_back(sp);
+  }
+  s->spans.clear();
+}
+
+extern "C" int cpmpc_profile_enable(cpmpc_solver* s, int on) {
+  if (!s) return fail(CPMPC_ERR_INVALID_ARG, "null solver");
+  s->profiling = on ? 1 : 0;
+  return CPMPC_OK;
+}
+extern "C" int cpmpc_profile_reset(cpmpc_solver* s) {
+  if (!s) return fail(CPMPC_ERR_INVALID_ARG, "null solver");
+  DeviceGuard guard(s->device);
+  collect_spans(s);
+  for (int i = 0; i < CPMPC_KERNEL_COUNT; ++i) {
+    s->prof_ms[i] = 0;
+    s->prof_n[i] = 0;
+  }
+  return CPMPC_OK;
+}
+extern "C" int cpmpc_profile_read(cpmpc_solver* s, int kernel, double* total_ms, int64_t* launches) {
+  if (!s || kernel < 0 || kernel >= CPMPC_KERNEL_COUNT) return fail(CPMPC_ERR_INVALID_ARG, "bad argument");
+  DeviceGuard guard(s->device);
+  collect_spans(s);
+  if (total_ms) *total_ms = s->prof_ms[kernel];
+  if (launches) *launches = s->prof_n[kernel];
+  return CPMPC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------------
+static inline dim3 grid_for(int64_t threads) { return dim3((unsigned)((threads + 63) / 64)); }
+
+template <typename R>
+static void fill_args(const cpmpc_solver* s, int64_t B, SolverArgs<R>& a) {
+  const cpmpc_params& p = s->params;
+  const cpmpc_solver_opts& o = s->opts;
+  memset(&a, 0, sizeof a);
+  a.B = B;
+  a.stride = s->cap;
+  a.N = s->N;
+  a.S = s->S;
+  a.SP = s->SP;
+  a.dt = (R)p.control_dt;
+  // rows exist only for strictly positive weights (optimization.cc:270,296)
+  a.wu = (R)(p.u_cost_weight > 0.0 ? p.u_cost_weight : 0.0);
+  a.wd = (R)(p.u_derivative_cost_weight > 0.0 ? p.u_derivative_cost_weight : 0.0);
+  const double w[4] = {p.b_x_final_cost_weight, p.th_final_cost_weight, p.b_x_dot_final_cost_weight,
+                       p.th_dot_final_cost_weight};
+  const double tgt[4] = {0.0, M_PI / 2, 0.0, 0.0};  // optimization.cc:236-267
+  a.term_is_cost = 0;
+  for (int t = 0; t < 4; ++t) {
+    const bool is_cost = w[t] >= 0.0;
+    a.term_w[t] = (R)(is_cost ? w[t] : 1.0);
+    a.term_tgt[t] = (R)tgt[t];
+    if (is_cost) a.term_is_cost |= (1 << t);
+  }
+  a.max_ls = o.max_line_search_iterations;
+  a.c1 = (R)o.armijo_c1;
+  a.shrink_max = (R)o.ls_shrink_max;
+  a.shrink_min = (R)o.ls_shrink_min;
+  a.rho = (R)o.penalty_rho;
+  a.lam_init = (R)o.lambda_initial;
+  a.lam_fail_init = (R)o.lambda_failure_init;
+  a.lam_up = (R)o.lambda_scale_up;
+  a.lam_down = (R)o.lambda_scale_down;
+  a.lam_min = (R)o.lambda_min;
+  a.lam_max = (R)o.lambda_max;
+  a.bx_lim = (R)o.b_x_limit;
+  a.u_lim = (R)o.u_limit;
+  a.rel_tol = (R)p.relative_exit_tol;
+  a.fo_tol = (R)p.absolute_first_derivative_tol;
+  a.mu_init = (R)p.equality_penalty_initial;
+  a.sin_amp = (R)p.u_guess_sinusoid_amplitude;
+  a.has_prev = s->has_prev;
+  a.z = (R*)s->z;
+  a.dz = (R*)s->dz;
+  a.Phi = (R*)s->Phi;
+  a.Gam = (R*)s->Gam;
+  a.cs = (R*)s->cs;
+  a.vv = (R*)s->vv;
+  a.uu = (R*)s->uu;
+  a.dd = (R*)s->dd;
+  a.sc = (R*)s->sc;
+  a.ist = s->ist;
+  a.sin_table = (const R*)s->sin_table;
+}
+
+template <typename R>
+static void launch_linearize(const SolverArgs<R>& a, int SP, const R* z_in, R* c_out, R* Phi_out, R* Gam_out,
+                             const int32_t* status, hipStream_t stream) {
+  const dim3 grid = grid_for(a.B * (a.S - 1));
+#define CPMPC_LIN(SPV)                                                                                     \
+  case SPV:                                                                                                \
+    hipLaunchKernelGGL((linearize_kernel<R, SPV>), grid, dim3(64), 0, stream, a, z_in, c_out, Phi_out,     \
+                       Gam_out, status);                                                                   \
+    break;
+  switch (SP) {
+    CPMPC_LIN(1)
+    CPMPC_LIN(2)
+    CPMPC_LIN(4)
+    CPMPC_LIN(5)
+    CPMPC_LIN(8)
+    CPMPC_LIN(10)
+    CPMPC_LIN(20)
+    default:
+      break;
+  }
+#undef CPMPC_LIN
+}
+
+template <typename R>
+static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* in, const cpmpc_step_outputs* out,
+                           hipStream_t stream) {
+  SolverArgs<R> a;
+  fill_args<R>(s, B, a);
+  a.x0 = (const R*)in->x0;
+  a.dyn = (const R*)in->dyn;
+  a.set_point = (const R*)in->set_point;
+  if (in->dyn == nullptr) {
+    a.consts = make_consts<R, double>(in->dyn_shared_host);
+  }
+  a.term_tgt[0] = (R)in->set_point_shared;
+  if (out) {
+    a.u_out = (R*)out->u;
+    a.pred_out = (R*)out->predicted;
+    a.status_out = out->status;
+    a.iters_out = out->iterations;
+    a.ls_out = out->ls_evals;
+    a.cost_out = (R*)out->final_cost;
+    a.eq_out = (R*)out->final_eq_l1;
+    a.guess_out = (R*)out->guess;
+  }
+  const dim3 gridB = grid_for(B);
+  ProfSpan sp;
+
+  span_begin(s, CPMPC_KERNEL_PREPARE, stream, &sp);
+  hipLaunchKernelGGL((prepare_kernel<R>), gridB, dim3(64), 0, stream, a);
+  span_end(s, stream, &sp);
+
+  for (int it = 0; it < (int)s->params.max_iterations; ++it) {
+    span_begin(s, CPMPC_KERNEL_LINEARIZE, stream, &sp);
+    launch_linearize<R>(a, s->SP, a.z, a.cs, a.Phi, a.Gam, a.ist, stream);
+    span_end(s, stream, &sp);
+    span_begin(s, CPMPC_KERNEL_QP_LS, stream, &sp);
+    hipLaunchKernelGGL((qp_ls_kernel<R>), gridB, dim3(64), 0, stream, a, it);
+    span_end(s, stream, &sp);
+  }
+
+  span_begin(s, CPMPC_KERNEL_FINALIZE, stream, &sp);
+  hipLaunchKernelGGL((finalize_kernel<R>), gridB, dim3(64), 0, stream, a);
+  span_end(s, stream, &sp);
+
+  HIP_TRY(hipGetLastError());
+  s->has_prev = 1;  // previous_solution_ = solver_->variables()  (optimization.cc:85)
+  return CPMPC_OK;
+}
+
+extern "C" int cpmpc_step_batch(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* in,
+                                const cpmpc_step_outputs* out, void* stream) {
+  if (!s || !in) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
+  if (B < 1) return fail(CPMPC_ERR_INVALID_ARG, "B must be >= 1");
+  if (B > s->cap) return fail(CPMPC_ERR_BATCH, "B=%lld exceeds the capacity %lld given to cpmpc_create", (long long)B, (long long)s->cap);
+  if (!in->x0) return fail(CPMPC_ERR_INVALID_ARG, "x0 is required");
+  if ((in->dyn_shared_host == nullptr) == (in->dyn == nullptr))
+    return fail(CPMPC_ERR_INVALID_ARG, "exactly one of dyn_shared_host / dyn must be given");
+  if (!in->set_point && !std::isfinite(in->set_point_shared))
+    return fail(CPMPC_ERR_INVALID_ARG, "set_point_shared must be finite");
+  DeviceGuard guard(s->device);
+  if (s->dtype == CPMPC_F32) return step_batch_impl<float>(s, B, in, out, (hipStream_t)stream);
+  return step_batch_impl<double>(s, B, in, out, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// warm-start state
+// ------------------------------------------------------------------------------------------------
+extern "C" int cpmpc_set_previous_solution(cpmpc_solver* s, int64_t B, const void* z, void* stream) {
+  if (!s || !z) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
+  if (B < 1 || B > s->cap) return fail(CPMPC_ERR_BATCH, "B out of range");
+  DeviceGuard guard(s->device);
+  // [dim][B] packed -> [dim][cap] strided
+  HIP_TRY(hipMemcpy2DAsync(s->z, (size_t)s->cap * s->esize, z, (size_t)B * s->esize, (size_t)B * s->esize,
+                           (size_t)s->dim, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  s->has_prev = 1;
+  return CPMPC_OK;
+}
+
+extern "C" int cpmpc_get_solution(cpmpc_solver* s, int64_t B, void* z_out, void* stream) {
+  if (!s || !z_out) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
+  if (B < 1 || B > s->cap) return fail(CPMPC_ERR_BATCH, "B out of range");
+  DeviceGuard guard(s->device);
+  HIP_TRY(hipMemcpy2DAsync(z_out, (size_t)B * s->esize, s->z, (size_t)s->cap * s->esize, (size_t)B * s->esize,
+                           (size_t)s->dim, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return CPMPC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-pointer convenience (staging copies around the same GPU path)
+// ------------------------------------------------------------------------------------------------
+static int ensure_stage(cpmpc_solver* s, size_t bytes) {
+  if (s->stage_bytes >= bytes) return CPMPC_OK;
+  if (s->stage) (void)hipFree(s->stage);
+  s->stage = nullptr;
+  s->stage_bytes = 0;
+  hipError_t e = hipMalloc(&s->stage, bytes);
+  if (e != hipSuccess) return fail(CPMPC_ERR_ALLOC, "hipMalloc of %zu staging bytes failed: %s", bytes, hipGetErrorString(e));
+  s->stage_bytes = bytes;
+  return CPMPC_OK;
+}
+
+template <typename R>
+static void to_dev_type(const double* src, size_t n, std::vector<R>& dst) {
+  dst.resize(n);
+  for (size_t i = 0; i < n; ++i) dst[i] = (R)src[i];
+}
+
+template <typename R>
+static int step_host_impl(cpmpc_solver* s, int64_t B, const double* x0_host, const double* dyn_shared_host,
+                          double set_point, double* u_host, double* predicted_host, int32_t* status_host,
+                          int32_t* iterations_host, double* final_cost_host, double* final_eq_l1_host) {
+  const size_t nB = (size_t)B;
+  const size_t n_x0 = 4 * nB, n_u = (size_t)s->N * nB, n_pred = 4 * (size_t)s->N * nB;
+  const size_t bytes = (n_x0 + n_u + n_pred + 2 * nB) * sizeof(R) + 2 * nB * sizeof(int32_t);
+  int rc = ensure_stage(s, bytes);
+  if (rc) return rc;
+  R* d_x0 = (R*)s->stage;
+  R* d_u = d_x0 + n_x0;
+  R* d_pred = d_u + n_u;
+  R* d_cost = d_pred + n_pred;
+  R* d_eq = d_cost + nB;
+  int32_t* d_status = (int32_t*)(d_eq + nB);
+  int32_t* d_iters = d_status + nB;
+
+  std::vector<R> h;
+  to_dev_type<R>(x0_host, n_x0, h);
+  HIP_TRY(hipMemcpy(d_x0, h.data(), n_x0 * sizeof(R), hipMemcpyHostToDevice));
+
+  cpmpc_step_inputs in;
+  memset(&in, 0, sizeof in);
+  in.x0 = d_x0;
+  in.dyn_shared_host = dyn_shared_host;
+  in.set_point_shared = set_point;
+  cpmpc_step_outputs out;
+  memset(&out, 0, sizeof out);
+  out.u = d_u;
+  out.predicted = predicted_host ? d_pred : nullptr;
+  out.status = d_status;
+  out.iterations = d_iters;
+  out.final_cost = d_cost;
+  out.final_eq_l1 = d_eq;
+  rc = step_batch_impl<R>(s, B, &in, &out, nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(nullptr));
+
+  auto fetch = [&](const R* dsrc, double* hdst, size_t n) -> int {
+    if (!hdst) return CPMPC_OK;
+    h.resize(n);
+    HIP_TRY(hipMemcpy(h.data(), dsrc, n * sizeof(R), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) hdst[i] = (double)h[i];
+    return CPMPC_OK;
+  };
+  if ((rc = fetch(d_u, u_host, n_u))) return rc;
+  if ((rc = fetch(d_pred, predicted_host, n_pred))) return rc;
+  if ((rc = fetch(d_cost, final_cost_host, nB))) return rc;
+  if ((rc = fetch(d_eq, final_eq_l1_host, nB))) return rc;
+  if (status_host) HIP_TRY(hipMemcpy(status_host, d_status, nB * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (iterations_host) HIP_TRY(hipMemcpy(iterations_host, d_iters, nB * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return CPMPC_OK;
+}
+
+extern "C" int cpmpc_step_batch_host(cpmpc_solver* s, int64_t B, const double* x0_host,
+                                     const double* dyn_shared_host, double set_point, double* u_host,
+                                     double* predicted_host, int32_t* status_host, int32_t* iterations_host,
+                                     double* final_cost_host, double* final_eq_l1_host) {
+  if (!s || !x0_host || !dyn_shared_host) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
+  if (B < 1) return fail(CPMPC_ERR_INVALID_ARG, "B must be >= 1");
+  if (B > s->cap) return fail(CPMPC_ERR_BATCH, "B exceeds capacity");
+  if (!std::isfinite(set_point)) return fail(CPMPC_ERR_INVALID_ARG, "set_point must be finite");
+  DeviceGuard guard(s->device);
+  if (s->dtype == CPMPC_F32)
+    return step_host_impl<float>(s, B, x0_host, dyn_shared_host, set_point, u_host, predicted_host, status_host,
+                                 iterations_host, final_cost_host, final_eq_l1_host);
+  return step_host_impl<double>(s, B, x0_host, dyn_shared_host, set_point, u_host, predicted_host, status_host,
+                                iterations_host, final_cost_host, final_eq_l1_host);
+}
+
+extern "C" int cpmpc_set_previous_solution_host(cpmpc_solver* s, int64_t B, const double* z_host) {
+  if (!s || !z_host) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
+  if (B < 1 || B > s->cap) return fail(CPMPC_ERR_BATCH, "B out of range");
+  DeviceGuard guard(s->device);
+  const size_t n = (size_t)s->dim * (size_t)B;
+  int rc = ensure_stage(s, n * s->esize);
+  if (rc) return rc;
+  if (s->dtype == CPMPC_F32) {
+    std::vector<float> h;
+    to_dev_type<float>(z_host, n, h);
+    HIP_TRY(hipMemcpy(s->stage, h.data(), n * 4, hipMemcpyHostToDevice));
+  } else {
+    HIP_TRY(hipMemcpy(s->stage, z_host, n * 8, hipMemcpyHostToDevice));
+  }
+  rc = cpmpc_set_previous_solution(s, B, s->stage, nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  return CPMPC_OK;
+}
+
+extern "C" int cpmpc_get_solution_host(cpmpc_solver* s, int64_t B, double* z_host) {
+  if (!s || !z_host) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
+  if (B < 1 || B > s->cap) return fail(CPMPC_ERR_BATCH, "B out of range");
+  DeviceGuard guard(s->device);
+  const size_t n = (size_t)s->dim * (size_t)B;
+  int rc = ensure_stage(s, n * s->esize);
+  if (rc) return rc;
+  rc = cpmpc_get_solution(s, B, s->stage, nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  if (s->dtype == CPMPC_F32) {
+    std::vector<float> h(n);
+    HIP_TRY(hipMemcpy(h.data(), s->stage, n * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) z_host[i] = (double)h[i];
+  } else {
+    HIP_TRY(hipMemcpy(z_host, s->stage, n * 8, hipMemcpyDeviceToHost));
+  }
+  return CPMPC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stand-alone pieces
+// ------------------------------------------------------------------------------------------------
+static int current_device_ok() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess)
+    return fail(CPMPC_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU fallback");
+  return check_device(dev);
+}
+
+template <typename R>
+static ExtForce<R> ext_from_host(const double* fext_host) {
+  ExtForce<R> fe{R(0), R(0), R(0)};
+  if (fext_host) {
+    fe.fbx = (R)fext_host[0];
+    fe.fmx = (R)fext_host[2];
+    fe.fmy = (R)fext_host[3];
+  }
+  return fe;
+}
+
+extern "C" int cpmpc_dynamics_batch(int dtype, int64_t B, const double* dyn_shared_host, const void* x,
+                                    const void* u, const double* fext_host, void* f, void* Jx, void* Ju,
+                                    void* stream) {
+  if (!dyn_shared_host || !x || !u || !f) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
+  if (B < 1) return fail(CPMPC_ERR_INVALID_ARG, "B must be >= 1");
+  int rc = current_device_ok();
+  if (rc) return rc;
+  if (dtype == CPMPC_F32) {
+    hipLaunchKernelGGL((dynamics_kernel<float>), grid_for(B), dim3(64), 0, (hipStream_t)stream, B,
+                       make_consts<float, double>(dyn_shared_host), ext_from_host<float>(fext_host),
+                       (const float*)x, (const float*)u, (float*)f, (float*)Jx, (float*)Ju);
+  } else if (dtype == CPMPC_F64) {
+    hipLaunchKernelGGL((dynamics_kernel<double>), grid_for(B), dim3(64), 0, (hipStream_t)stream, B,
+                       make_consts<double, double>(dyn_shared_host), ext_from_host<double>(fext_host),
+                       (const double*)x, (const double*)u, (double*)f, (double*)Jx, (double*)Ju);
+  } else {
+    return fail(CPMPC_ERR_INVALID_ARG, "bad dtype");
+  }
+  HIP_TRY(hipGetLastError());
+  return CPMPC_OK;
+}
+
+extern "C" int cpmpc_rk4_batch(int dtype, int64_t B, const double* dyn_shared_host, const void* x, const void* u,
+                               double h, const double* fext_host, void* x_new, void* A, void* Bm, void* stream) {
+  if (!dyn_shared_host || !x || !u || !x_new) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
+  if (B < 1) return fail(CPMPC_ERR_INVALID_ARG, "B must be >= 1");
+  int rc = current_device_ok();
+  if (rc) return rc;
+  if (dtype == CPMPC_F32) {
+    hipLaunchKernelGGL((rk4_kernel<float>), grid_for(B), dim3(64), 0, (hipStream_t)stream, B,
+                       make_consts<float, double>(dyn_shared_host), ext_from_host<float>(fext_host), (float)h,
+                       (const float*)x, (const float*)u, (float*)x_new, (float*)A, (float*)Bm);
+  } else if (dtype == CPMPC_F64) {
+    hipLaunchKernelGGL((rk4_kernel<double>), grid_for(B), dim3(64), 0, (hipStream_t)stream, B,
+                       make_consts<double, double>(dyn_shared_host), ext_from_host<double>(fext_host), h,
+                       (const double*)x, (const double*)u, (double*)x_new, (double*)A, (double*)Bm);
+  } else {
+    return fail(CPMPC_ERR_INVALID_ARG, "bad dtype");
+  }
+  HIP_TRY(hipGetLastError());
+  return CPMPC_OK;
+}
+
+extern "C" int cpmpc_linearize_batch(cpmpc_solver* s, int64_t B, const double* dyn_shared_host, const void* z,
+                                     void* c, void* Phi, void* Gamma, void* stream) {
+  if (!s || !dyn_shared_host || !z || !c || !Phi || !Gamma) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
+  if (B < 1) return fail(CPMPC_ERR_INVALID_ARG, "B must be >= 1");
+  DeviceGuard guard(s->device);
+  if (s->dtype == CPMPC_F32) {
+    SolverArgs<float> a;
+    fill_args<float>(s, B, a);
+    a.stride = B;  // caller arrays are packed [field][B]
+    a.consts = make_consts<float, double>(dyn_shared_host);
+    launch_linearize<float>(a, s->SP, (const float*)z, (float*)c, (float*)Phi, (float*)Gamma, nullptr,
+                            (hipStream_t)stream);
+  } else {
+    SolverArgs<double> a;
+    fill_args<double>(s, B, a);
+    a.stride = B;
+    a.consts = make_consts<double, double>(dyn_shared_host);
+    launch_linearize<double>(a, s->SP, (const double*)z, (double*)c, (double*)Phi, (double*)Gamma, nullptr,
+                             (hipStream_t)stream);
+  }
+  HIP_TRY(hipGetLastError());
+  return CPMPC_OK;
+}
+
+extern "C" int cpmpc_sim_step_batch(int dtype, int64_t B, const double* dyn_shared_host, double dt, const void* u,
+                                    const double* fext_host, const void* fext, void* state, void* stream) {
+  if (!dyn_shared_host || !u || !state) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
+  if (B < 1) return fail(CPMPC_ERR_INVALID_ARG, "B must be >= 1");
+  if (!(dt >= 0.0) || !std::isfinite(dt)) return fail(CPMPC_ERR_INVALID_ARG, "dt must be finite and >= 0 (simulator.cc:13)");
+  int rc = current_device_ok();
+  if (rc) return rc;
+  // simulator.cc:18-22 evaluated in double: number of sub-steps and the size of the last one
+  const double internal_dt = 0.001;
+  int n_sub = 0;
+  double h_last = internal_dt;
+  {
+    double rem = dt;
+    while (rem > 0.0) {
+      h_last = rem < internal_dt ? rem : internal_dt;
+      ++n_sub;
+      rem -= internal_dt;
+      if (n_sub > 100000000) return fail(CPMPC_ERR_INVALID_ARG, "dt too large");
+    }
+  }
+  if (n_sub == 0) return CPMPC_OK;
+  if (dtype == CPMPC_F32) {
+    hipLaunchKernelGGL((sim_kernel<float>), grid_for(B), dim3(64), 0, (hipStream_t)stream, B,
+                       make_consts<float, double>(dyn_shared_host), ext_from_host<float>(fext_host),
+                       (const float*)fext, n_sub, (float)h_last, (const float*)u, (float*)state);
+  } else if (dtype == CPMPC_F64) {
+    hipLaunchKernelGGL((sim_kernel<double>), grid_for(B), dim3(64), 0, (hipStream_t)stream, B,
+                       make_consts<double, double>(dyn_shared_host), ext_from_host<double>(fext_host),
+                       (const double*)fext, n_sub, h_last, (const double*)u, (double*)state);
+  } else {
+    return fail(CPMPC_ERR_INVALID_ARG, "bad dtype");
+  }
+  HIP_TRY(hipGetLastError());
+  return CPMPC_OK;
+}

@@ -1,0 +1,815 @@
+// mpc_kernels.hpp -- the batched MPC inner loop as gfx950 kernels, one problem per lane.
+//
+// Pipeline of one batched re-plan (host loop in cpmpc_api.hip; reference: Optimization::Step,
+// optimization/optimization.cc:39-97):
+//
+//   prepare_kernel      guess (warm shift / sinusoid) + FillInitialGuess      optimization.cc:46-71,333-351
+//   repeat max_iterations times:
+//     linearize_kernel  every shooting interval: RK4 + sensitivities          optimization.cc:99-160
+//     qp_ls_kernel      structured equality-constrained QP + merit line search (role of mini_opt)
+//   finalize_kernel     ComputePredictedStates + outputs                      optimization.cc:85-96,353-371
+//
+// Data layout in HBM: structure-of-arrays, field-major with the problem index fastest, so that lane
+// i of a wave touches address base + field*stride + i -> every access is one coalesced 256 B (f32)
+// or 512 B (f64) wave transaction.  No LDS: per-lane state lives in VGPRs, the per-interval
+// sensitivities (Phi, Gamma) stream through the workspace once per SQP iteration.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cartpole_device.hpp"
+
+namespace cpmpc {
+
+constexpr int kTermNone = 0;
+constexpr int kTermMaxIterations = 1;
+constexpr int kTermRelTol = 3;
+constexpr int kTermFirstOrder = 4;
+constexpr int kTermQpIndefinite = 5;
+constexpr int kTermMaxLambda = 7;
+constexpr int kTermNonFinite = 8;
+
+// per-problem real scalars kept in the workspace (index into `sc`)
+enum { SC_LAMBDA = 0, SC_MU, SC_F_LAST, SC_CN_LAST, SC_UPREV, SC_COUNT };
+// per-problem int scalars (index into `ist`)
+enum { IS_STATUS = 0, IS_ITERS, IS_LS_EVALS, IS_FAILED, IS_COUNT };
+
+template <typename R>
+struct SolverArgs {
+  // sizes
+  int64_t B;       // problems in this call
+  int64_t stride;  // elements between consecutive fields (capacity of the workspace)
+  int N, S, SP;
+  R dt;
+  // cost weights (optimization.hpp:40-48)
+  R wu, wd;         // u_cost_weight, u_derivative_cost_weight (0 disables the rows)
+  R term_w[4];      // residual weight of terminal row t (1 for an equality row)
+  R term_tgt[4];    // targets; [0] is the shared set-point unless set_point != nullptr
+  int term_is_cost; // bit t set: terminal row t is a cost (weight >= 0), else an equality
+  // solver options
+  int max_ls;
+  R c1, shrink_max, shrink_min, rho;
+  R lam_init, lam_fail_init, lam_up, lam_down, lam_min, lam_max;
+  R bx_lim, u_lim;
+  R rel_tol, fo_tol, mu_init;
+  R sin_amp;
+  int has_prev;
+  // workspace (device)
+  R* z;     // [4S+N]   iterate; persists between calls as the warm start
+  R* dz;    // [4S+N]   QP step
+  R* Phi;   // [16(S-1)]
+  R* Gam;   // [4N]     element (r,k) at field 4k+r
+  R* cs;    // [4(S-1)] shooting defects
+  R* vv;    // [N]      tridiagonal solve scratch
+  R* uu;    // [N]
+  R* dd;    // [N]
+  R* sc;    // [SC_COUNT]
+  int32_t* ist;  // [IS_COUNT]
+  const R* sin_table;  // [N] device: u_guess_sinusoid_amplitude * sin(2 pi k / N), from the host
+  // inputs
+  const R* x0;         // [4]
+  const R* dyn;        // [9] per-problem, or nullptr
+  const R* set_point;  // [1] per-problem, or nullptr
+  CartPoleConsts<R> consts;  // shared model constants (used when dyn == nullptr)
+  // outputs (nullable)
+  R* u_out;
+  R* pred_out;
+  int32_t* status_out;
+  int32_t* iters_out;
+  int32_t* ls_out;
+  R* cost_out;
+  R* eq_out;
+  R* guess_out;
+};
+
+template <typename R>
+__device__ __forceinline__ CartPoleConsts<R> load_consts(const SolverArgs<R>& a, int64_t p) {
+  if (a.dyn == nullptr) return a.consts;
+  R prm[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) prm[i] = a.dyn[i * a.B + p];  // inputs are packed [field][B]
+  return make_consts<R, R>(prm);
+}
+
+template <typename R>
+__device__ __forceinline__ R clampr(R v, R lo, R hi) {
+  return v < lo ? lo : (v > hi ? hi : v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// prepare: initial guess.  One thread per problem.
+// ------------------------------------------------------------------------------------------------
+template <typename R>
+__global__ __launch_bounds__(64) void prepare_kernel(const SolverArgs<R> a) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= a.B) return;
+  const int64_t st = a.stride;
+  const CartPoleConsts<R> k = load_consts(a, p);
+  const ExtForce<R> fe{R(0), R(0), R(0)};
+  R* zu = a.z + (int64_t)4 * a.S * st + p;
+
+  // BuildProblem reads u_prev before the previous solution is overwritten (optimization.cc:288-291)
+  R u_prev = R(0);
+  if (a.has_prev) {
+    u_prev = zu[0];
+    // shift the controls left by one, duplicate the last (optimization.cc:54-57)
+    for (int kk = 0; kk + 1 < a.N; ++kk) zu[(int64_t)kk * st] = zu[(int64_t)(kk + 1) * st];
+  } else {
+    for (int kk = 0; kk < a.N; ++kk) zu[(int64_t)kk * st] = a.sin_table[kk];
+  }
+  a.sc[SC_UPREV * st + p] = u_prev;
+  a.sc[SC_LAMBDA * st + p] = a.lam_init;
+  a.sc[SC_MU * st + p] = a.mu_init;
+  a.sc[SC_F_LAST * st + p] = R(0);
+  a.sc[SC_CN_LAST * st + p] = R(0);
+  a.ist[IS_STATUS * st + p] = kTermNone;
+  a.ist[IS_ITERS * st + p] = 0;
+  a.ist[IS_LS_EVALS * st + p] = 0;
+  a.ist[IS_FAILED * st + p] = 0;
+
+  // FillInitialGuess (optimization.cc:333-351): roll the states, wrapping after every step
+  R x[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    x[t] = a.x0[t * a.B + p];
+    a.z[t * st + p] = x[t];
+  }
+  for (int s = 1; s < a.S; ++s) {
+    for (int i = 0; i < a.SP; ++i) {
+      const R u = zu[(int64_t)((s - 1) * a.SP + i) * st];
+      rk4_step<R, false>(k, a.dt, x, u, fe);
+      x[1] = mod_pi(x[1]);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a.z[(int64_t)(4 * s + t) * st + p] = x[t];
+  }
+  if (a.guess_out) {
+    const int dim = 4 * a.S + a.N;
+    for (int i = 0; i < dim; ++i) a.guess_out[(int64_t)i * a.B + p] = a.z[(int64_t)i * st + p];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// linearize: one thread per (problem, shooting interval).
+// Integrates x_s through SP controls with RK4, accumulating Phi = dx_end/dx_s and
+// Gamma = dx_end/du FORWARD (Phi <- A Phi, Gamma_j <- A Gamma_j, Gamma_i = B) so that nothing per
+// step has to be stored: the 4 x SP block lives in registers with static indices.  Algebraically
+// equal to the reference's backward accumulation (optimization.cc:145-154).
+// ------------------------------------------------------------------------------------------------
+template <typename R, int SP>
+__global__ __launch_bounds__(64) void linearize_kernel(const SolverArgs<R> a, const R* z_in,
+                                                        R* c_out, R* Phi_out, R* Gam_out,
+                                                        const int32_t* status) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t s64 = gid / a.B;
+  const int64_t p = gid - s64 * a.B;
+  const int s = (int)s64;
+  if (s >= a.S - 1) return;
+  const int64_t st = a.stride;
+  if (status != nullptr && status[IS_STATUS * st + p] != kTermNone) return;
+  const CartPoleConsts<R> k = load_consts(a, p);
+  const ExtForce<R> fe{R(0), R(0), R(0)};
+
+  R x[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) x[t] = z_in[(int64_t)(4 * s + t) * st + p];
+  R Phi[4][4];
+  R Gam[SP][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) Phi[r][c] = (r == c) ? R(1) : R(0);
+#pragma unroll
+  for (int j = 0; j < SP; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Gam[j][r] = R(0);
+
+  const R* zu = z_in + (int64_t)(4 * a.S + s * SP) * st + p;
+  R u_next = zu[0];
+#pragma unroll 1
+  for (int i = 0; i < SP; ++i) {
+    const R u = u_next;
+    if (i + 1 < SP) u_next = zu[(int64_t)(i + 1) * st];  // prefetch the next control
+    R A[4][4], Bv[4];
+    rk4_step_jac<R, false>(k, a.dt, x, u, fe, A, Bv);
+    // Phi <- A Phi
+    R T[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        T[r][c] = A[r][0] * Phi[0][c] + A[r][1] * Phi[1][c] + A[r][2] * Phi[2][c] + A[r][3] * Phi[3][c];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) Phi[r][c] = T[r][c];
+      // Gamma columns: j < i propagate, j == i is the new control's column.  `i` is uniform over
+      // the wave, so these are scalar branches and the register indices stay static.
+#pragma unroll
+    for (int j = 0; j < SP; ++j) {
+      if (j < i) {
+        R g0 = Gam[j][0], g1 = Gam[j][1], g2 = Gam[j][2], g3 = Gam[j][3];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Gam[j][r] = A[r][0] * g0 + A[r][1] * g1 + A[r][2] * g2 + A[r][3] * g3;
+      } else if (j == i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Gam[j][r] = Bv[r];
+      }
+    }
+  }
+  // wrap the angle once at the end of the interval, then the defect (optimization.cc:139,156-157)
+  x[1] = mod_pi(x[1]);
+  R c[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) c[t] = x[t] - z_in[(int64_t)(4 * (s + 1) + t) * st + p];
+  c[1] = mod_pi(c[1]);
+
+#pragma unroll
+  for (int t = 0; t < 4; ++t) c_out[(int64_t)(4 * s + t) * st + p] = c[t];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) Phi_out[(int64_t)(16 * s + 4 * r + cc) * st + p] = Phi[r][cc];
+#pragma unroll
+  for (int j = 0; j < SP; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Gam_out[(int64_t)(4 * (s * SP + j) + r) * st + p] = Gam[j][r];
+}
+
+// ------------------------------------------------------------------------------------------------
+// merit evaluation at z (+) alpha dz: 1/2 |r|^2 and |c|_1 through the retraction
+// (optimization.cc:309-329) and a no-Jacobian rollout of every interval (optimization.cc:130-139).
+// ------------------------------------------------------------------------------------------------
+template <typename R>
+__device__ __forceinline__ void merit_eval(const SolverArgs<R>& a, const CartPoleConsts<R>& k,
+                                           const int64_t p, const R alpha, const R (&xm)[4],
+                                           const R (&tgt)[4], const R u_prev, R& f_out, R& cn_out) {
+  const int64_t st = a.stride;
+  const ExtForce<R> fe{R(0), R(0), R(0)};
+  const int64_t uoff = (int64_t)4 * a.S;
+  R f = R(0), cn = R(0);
+
+  // node 0 and the initial-state equality rows (optimization.cc:228-232)
+  R xs[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) xs[t] = a.z[t * st + p] + alpha * a.dz[t * st + p];
+  xs[1] = mod_pi(xs[1]);
+  xs[0] = clampr(xs[0], -a.bx_lim, a.bx_lim);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    R d = xs[t] - xm[t];
+    if (t == 1) d = mod_pi(d);
+    cn += Math<R>::fabs(d);
+  }
+
+  R u_before = u_prev;  // u_{k-1} of the trial point, for the du rows
+  int kk = 0;
+  for (int s = 0; s + 1 < a.S; ++s) {
+    R x[4] = {xs[0], xs[1], xs[2], xs[3]};
+    for (int i = 0; i < a.SP; ++i, ++kk) {
+      R u = a.z[(uoff + kk) * st + p] + alpha * a.dz[(uoff + kk) * st + p];
+      u = clampr(u, -a.u_lim, a.u_lim);
+      // control cost rows (optimization.cc:270-301)
+      const R ru = a.wu * u;
+      f += ru * ru;
+      const R rd = a.wd * (u_before - u);  // (u_{k-1} - u_k) w; for k = 0 it is -(u_0 - u_prev) w
+      f += rd * rd;
+      u_before = u;
+      rk4_step<R, false>(k, a.dt, x, u, fe);
+    }
+    x[1] = mod_pi(x[1]);
+    // next node of the trial point
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      xs[t] = a.z[(int64_t)(4 * (s + 1) + t) * st + p] + alpha * a.dz[(int64_t)(4 * (s + 1) + t) * st + p];
+    xs[1] = mod_pi(xs[1]);
+    xs[0] = clampr(xs[0], -a.bx_lim, a.bx_lim);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      R d = x[t] - xs[t];
+      if (t == 1) d = mod_pi(d);
+      cn += Math<R>::fabs(d);
+    }
+  }
+  // terminal rows on the last node (optimization.cc:236-267)
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    R d = xs[t] - tgt[t];
+    if (t == 1) d = mod_pi(d);
+    if ((a.term_is_cost >> t) & 1) {
+      const R r = a.term_w[t] * d;
+      f += r * r;
+    } else {
+      cn += Math<R>::fabs(d);
+    }
+  }
+  f_out = R(0.5) * f;
+  cn_out = cn;
+}
+
+// ------------------------------------------------------------------------------------------------
+// qp_ls: one thread per problem.  Solves
+//     min 1/2 |J dz + r|^2 + 1/2 lambda |du|^2   s.t.  A dz + c = 0
+// exactly, without forming it: the states are eliminated through the shooting recursion
+//     dx_0 = -c_init,  dx_{s+1} = Phi_s dx_s + Gamma_s du_s + c_s,
+// which leaves a QP in du whose Hessian is T + R^T R with T tridiagonal (control costs) and R the
+// <= 4 terminal rows (cost or equality).  T = U D U^T is factorised by a scalar recurrence, the
+// terminal rows by a 4x4 LDL^T of  S + Dg,  S = R T^-1 R^T, all in registers; Gamma streams from
+// the workspace three times (S, the gradient, the state recovery).  Then the l1-merit penalty
+// update and the Armijo line search with quadratic-interpolation backtracking.
+// ------------------------------------------------------------------------------------------------
+template <typename R>
+__global__ __launch_bounds__(64) void qp_ls_kernel(const SolverArgs<R> a, const int iter_index) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= a.B) return;
+  const int64_t st = a.stride;
+  if (a.ist[IS_STATUS * st + p] != kTermNone) return;
+  (void)iter_index;
+  const CartPoleConsts<R> k = load_consts(a, p);
+  const int N = a.N, S = a.S, SP = a.SP;
+  const int64_t uoff = (int64_t)4 * S;
+  const R* zu = a.z + uoff * st + p;
+
+  R lam = a.sc[SC_LAMBDA * st + p];
+  R mu = a.sc[SC_MU * st + p];
+  const R u_prev = a.sc[SC_UPREV * st + p];
+  R tgt[4] = {a.term_tgt[0], a.term_tgt[1], a.term_tgt[2], a.term_tgt[3]};
+  if (a.set_point) tgt[0] = a.set_point[p];
+  R xm[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) xm[t] = a.x0[t * a.B + p];
+
+  const R wu2 = a.wu * a.wu, wd2 = a.wd * a.wd;
+
+  // ---- residuals at z: cost f, constraint l1 norm, a = dx_{S-1} with du = 0 ---------------------
+  R f = R(0), cn = R(0);
+  R av[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    R d = a.z[t * st + p] - xm[t];
+    if (t == 1) d = mod_pi(d);
+    cn += Math<R>::fabs(d);
+    av[t] = -d;
+  }
+  for (int s = 0; s + 1 < S; ++s) {
+    R cs[4], nv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      cs[t] = a.cs[(int64_t)(4 * s + t) * st + p];
+      cn += Math<R>::fabs(cs[t]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      R acc = cs[r];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc += a.Phi[(int64_t)(16 * s + 4 * r + c) * st + p] * av[c];
+      nv[r] = acc;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) av[t] = nv[t];
+  }
+  R hv[4], Rw[4], Dg[4], e_term[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    R d = a.z[(int64_t)(4 * (S - 1) + t) * st + p] - tgt[t];
+    if (t == 1) d = mod_pi(d);
+    e_term[t] = d;
+    const bool is_cost = (a.term_is_cost >> t) & 1;
+    Rw[t] = a.term_w[t];
+    Dg[t] = is_cost ? R(1) : R(0);
+    if (is_cost) {
+      const R r = a.term_w[t] * d;
+      f += r * r;
+    } else {
+      cn += Math<R>::fabs(d);
+    }
+    hv[t] = Rw[t] * (d + av[t]);
+  }
+  {
+    R ub = u_prev;
+    for (int kk = 0; kk < N; ++kk) {
+      const R u = zu[(int64_t)kk * st];
+      const R ru = a.wu * u, rd = a.wd * (ub - u);
+      f += ru * ru + rd * rd;
+      ub = u;
+    }
+  }
+  f *= R(0.5);
+
+  int status = kTermNone;
+  if (!Math<R>::finite(f) || !Math<R>::finite(cn)) status = kTermNonFinite;
+
+  // ---- pass 1 (k descending): T = U D U^T on the fly, S = R T^-1 R^T, rho = R T^-1 g ------------
+  R Sm[4][4], rho[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    rho[i] = R(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Sm[i][j] = R(0);
+  }
+  bool pd_ok = true;
+  {
+    R Psi[4][4];  // diag(Rw) Phi_{S-2} ... Phi_{s+1}
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) Psi[r][c] = (r == c) ? Rw[r] : R(0);
+    R wprev[4] = {R(0), R(0), R(0), R(0)};
+    R gwprev = R(0);
+    R d_next = R(1), ups = R(0);
+    R u_hi = R(0);                        // u_{k+1}
+    R u_cur = zu[(int64_t)(N - 1) * st];  // u_k
+    int kk = N - 1;
+    for (int s = S - 2; s >= 0; --s) {
+      for (int i = SP - 1; i >= 0; --i, --kk) {
+        const R u_lo = (kk > 0) ? zu[(int64_t)(kk - 1) * st] : u_prev;  // u_{k-1} (u_prev for k = 0)
+        // tridiagonal entries and the control-cost gradient g_k
+        const R nd = (kk < N - 1 ? R(1) : R(0)) + R(1);  // du rows touching u_k: (k,k+1) and (k-1,k)|(0,prev)
+        const R diag = wu2 + lam + wd2 * nd;
+        R g = wu2 * u_cur + wd2 * (u_cur - u_lo);
+        if (kk < N - 1) g += wd2 * (u_cur - u_hi);
+        // U D U^T recurrence
+        ups = (kk < N - 1) ? (-wd2 / d_next) : R(0);
+        const R dk = diag + wd2 * ups;  // diag - off*ups with off = -wd2
+        if (!(dk > R(0))) pd_ok = false;
+        const R inv_d = R(1) / dk;
+        a.uu[(int64_t)kk * st + p] = ups;
+        a.dd[(int64_t)kk * st + p] = inv_d;
+        d_next = dk;
+        // m_k = Psi Gamma_k ; w_k = m_k - ups w_{k+1}
+        R gk[4], wk[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gk[r] = a.Gam[(int64_t)(4 * kk + r) * st + p];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const R m = Psi[r][0] * gk[0] + Psi[r][1] * gk[1] + Psi[r][2] * gk[2] + Psi[r][3] * gk[3];
+          wk[r] = m - ups * wprev[r];
+        }
+        const R gw = g - ups * gwprev;
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2) {
+          const R wi = wk[i2] * inv_d;
+          rho[i2] += wi * gw;
+#pragma unroll
+          for (int j2 = 0; j2 <= i2; ++j2) Sm[i2][j2] += wi * wk[j2];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wprev[r] = wk[r];
+        gwprev = gw;
+        u_hi = u_cur;
+        u_cur = u_lo;
+      }
+      // Psi <- Psi Phi_s
+      R Ph[4][4], T[4][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Ph[r][c] = a.Phi[(int64_t)(16 * s + 4 * r + c) * st + p];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          T[r][c] = Psi[r][0] * Ph[0][c] + Psi[r][1] * Ph[1][c] + Psi[r][2] * Ph[2][c] + Psi[r][3] * Ph[3][c];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Psi[r][c] = T[r][c];
+    }
+  }
+
+  // ---- (S + Dg) q = h - rho by LDL^T on the lower triangle, in registers ------------------------
+  R q[4];
+  {
+    R Lm[4][4], dv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Sm[i][i] += Dg[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      R dj = Sm[j][j];
+#pragma unroll
+      for (int m = 0; m < j; ++m) dj -= Lm[j][m] * Lm[j][m] * dv[m];
+      if (!(dj > R(0))) pd_ok = false;
+      dv[j] = dj;
+      const R inv = R(1) / dj;
+#pragma unroll
+      for (int i = j + 1; i < 4; ++i) {
+        R v = Sm[i][j];
+#pragma unroll
+        for (int m = 0; m < j; ++m) v -= Lm[i][m] * Lm[j][m] * dv[m];
+        Lm[i][j] = v * inv;
+      }
+    }
+    R y[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      R v = hv[i] - rho[i];
+#pragma unroll
+      for (int m = 0; m < i; ++m) v -= Lm[i][m] * y[m];
+      y[i] = v;
+    }
+#pragma unroll
+    for (int i = 3; i >= 0; --i) {
+      R v = y[i] / dv[i];
+#pragma unroll
+      for (int m = i + 1; m < 4; ++m) v -= Lm[m][i] * q[m];
+      q[i] = v;
+    }
+  }
+  if (status == kTermNone && !pd_ok) status = kTermQpIndefinite;
+
+  // ---- pass 2 (k descending): b = g + R^T q ; U y = -b ; v = D^-1 y -----------------------------
+  {
+    R psi[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) psi[r] = Rw[r] * q[r];
+    R yprev = R(0);
+    R u_hi = R(0);
+    R u_cur = zu[(int64_t)(N - 1) * st];
+    int kk = N - 1;
+    for (int s = S - 2; s >= 0; --s) {
+      for (int i = SP - 1; i >= 0; --i, --kk) {
+        const R u_lo = (kk > 0) ? zu[(int64_t)(kk - 1) * st] : u_prev;
+        R g = wu2 * u_cur + wd2 * (u_cur - u_lo);
+        if (kk < N - 1) g += wd2 * (u_cur - u_hi);
+        R b = g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b += psi[r] * a.Gam[(int64_t)(4 * kk + r) * st + p];
+        const R ups = a.uu[(int64_t)kk * st + p];
+        const R inv_d = a.dd[(int64_t)kk * st + p];
+        const R y = -b - ups * yprev;
+        a.vv[(int64_t)kk * st + p] = y * inv_d;
+        yprev = y;
+        u_hi = u_cur;
+        u_cur = u_lo;
+      }
+      // psi <- Phi_s^T psi
+      R np[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        R acc = R(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc += a.Phi[(int64_t)(16 * s + 4 * r + c) * st + p] * psi[r];
+        np[c] = acc;
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) psi[c] = np[c];
+    }
+  }
+
+  // ---- pass 3 (k ascending): U^T du = v ; state recovery ; directional quantities ---------------
+  R gd = R(0), curv = R(0);
+  {
+    R dx[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      R d = a.z[t * st + p] - xm[t];
+      if (t == 1) d = mod_pi(d);
+      dx[t] = -d;
+      a.dz[t * st + p] = dx[t];
+    }
+    R du_prev = R(0);   // du_{k-1}; the (u_0 - u_prev) row sees only du_0
+    R u_lo = u_prev;    // u_{k-1}
+    R u_cur = zu[0];
+    int kk = 0;
+    for (int s = 0; s + 1 < S; ++s) {
+      R acc[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        R v = a.cs[(int64_t)(4 * s + r) * st + p];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v += a.Phi[(int64_t)(16 * s + 4 * r + c) * st + p] * dx[c];
+        acc[r] = v;
+      }
+      for (int i = 0; i < SP; ++i, ++kk) {
+        const R ups_lo = (kk > 0) ? a.uu[(int64_t)(kk - 1) * st + p] : R(0);
+        const R du = a.vv[(int64_t)kk * st + p] - ups_lo * du_prev;
+        a.dz[(uoff + kk) * st + p] = du;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] += a.Gam[(int64_t)(4 * kk + r) * st + p] * du;
+        const R u_hi = (kk + 1 < N) ? zu[(int64_t)(kk + 1) * st] : R(0);
+        R g = wu2 * u_cur + wd2 * (u_cur - u_lo);
+        if (kk < N - 1) g += wd2 * (u_cur - u_hi);
+        gd += g * du;
+        const R jd = a.wd * (du_prev - du);  // rows (u_{k-1} - u_k) w and, for k = 0, (u_0 - u_prev) w
+        curv += wu2 * du * du + jd * jd + lam * du * du;
+        du_prev = du;
+        u_lo = u_cur;
+        u_cur = u_hi;
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        dx[t] = acc[t];
+        a.dz[(int64_t)(4 * (s + 1) + t) * st + p] = dx[t];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if ((a.term_is_cost >> t) & 1) {
+        const R jd = a.term_w[t] * dx[t];
+        gd += (a.term_w[t] * e_term[t]) * jd;
+        curv += jd * jd;
+      }
+    }
+  }
+  if (status == kTermNone && (!Math<R>::finite(gd) || !Math<R>::finite(curv))) status = kTermQpIndefinite;
+
+  // ---- penalty update (Nocedal & Wright 18.36, sigma = 1), merit slope --------------------------
+  if (cn > R(0)) {
+    const R mu_req = (gd + R(0.5) * curv) / ((R(1) - a.rho) * cn);
+    if (mu < mu_req) mu = mu_req;
+  }
+  const R D = gd - mu * cn;
+  const R phi0 = f + mu * cn;
+  const bool first_order = Math<R>::fabs(D) < a.fo_tol;
+
+  // ---- Armijo line search, lock-step over the wave ----------------------------------------------
+  bool active = (status == kTermNone);
+  bool accepted = false;
+  R alpha = R(1), phi_t = R(0), f_t = f, cn_t = cn;
+  int evals = 0;
+  for (int t = 0; t < a.max_ls; ++t) {
+    if (!__any(active)) break;
+    if (active) {
+      R ft, ct;
+      merit_eval<R>(a, k, p, alpha, xm, tgt, u_prev, ft, ct);
+      ++evals;
+      phi_t = ft + mu * ct;
+      if (phi_t <= phi0 + a.c1 * alpha * D) {
+        accepted = true;
+        active = false;
+        f_t = ft;
+        cn_t = ct;
+      } else {
+        const R denom = R(2) * (phi_t - phi0 - D * alpha);
+        R a_new = (denom > R(0)) ? (-D * alpha * alpha / denom) : (a.shrink_max * alpha);
+        if (!(a_new >= a.shrink_min * alpha)) a_new = a.shrink_min * alpha;
+        if (a_new > a.shrink_max * alpha) a_new = a.shrink_max * alpha;
+        alpha = a_new;
+      }
+    }
+  }
+
+  // ---- accept / reject, damping schedule, termination -------------------------------------------
+  int failed = a.ist[IS_FAILED * st + p];
+  if (status == kTermNone) {
+    if (accepted) {
+      const int dim = 4 * S + N;
+      for (int s = 0; s < S; ++s) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int64_t idx = (int64_t)(4 * s + t) * st + p;
+          R v = a.z[idx] + alpha * a.dz[idx];
+          if (t == 1) v = mod_pi(v);
+          if (t == 0) v = clampr(v, -a.bx_lim, a.bx_lim);
+          a.z[idx] = v;
+        }
+      }
+      for (int i = 4 * S; i < dim; ++i) {
+        const int64_t idx = (int64_t)i * st + p;
+        a.z[idx] = clampr(a.z[idx] + alpha * a.dz[idx], -a.u_lim, a.u_lim);
+      }
+      lam *= a.lam_down;
+      if (lam < a.lam_min) lam = R(0);
+    }
+    if (first_order) {
+      status = kTermFirstOrder;
+    } else if (accepted) {
+      if ((phi0 - phi_t) < a.rel_tol * phi0) status = kTermRelTol;
+    } else {
+      ++failed;
+      lam = (lam > R(0)) ? lam * a.lam_up : a.lam_fail_init;
+      if (lam > a.lam_max) status = kTermMaxLambda;
+    }
+  }
+  if (status != kTermNonFinite) a.ist[IS_ITERS * st + p] += 1;
+  a.sc[SC_LAMBDA * st + p] = lam;
+  a.sc[SC_MU * st + p] = mu;
+  a.sc[SC_F_LAST * st + p] = f_t;
+  a.sc[SC_CN_LAST * st + p] = cn_t;
+  a.ist[IS_STATUS * st + p] = status;
+  a.ist[IS_LS_EVALS * st + p] += evals;
+  a.ist[IS_FAILED * st + p] = failed;
+}
+
+// ------------------------------------------------------------------------------------------------
+// finalize: predicted states (optimization.cc:353-371) and outputs.  One thread per problem.
+// ------------------------------------------------------------------------------------------------
+template <typename R>
+__global__ __launch_bounds__(64) void finalize_kernel(const SolverArgs<R> a) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= a.B) return;
+  const int64_t st = a.stride;
+  const int64_t ob = a.B;  // outputs are packed [field][B]
+  const R* zu = a.z + (int64_t)4 * a.S * st + p;
+  int status = a.ist[IS_STATUS * st + p];
+  if (status == kTermNone) status = kTermMaxIterations;
+  if (a.status_out) a.status_out[p] = status;
+  if (a.iters_out) a.iters_out[p] = a.ist[IS_ITERS * st + p];
+  if (a.ls_out) a.ls_out[p] = a.ist[IS_LS_EVALS * st + p];
+  if (a.cost_out) a.cost_out[p] = a.sc[SC_F_LAST * st + p];
+  if (a.eq_out) a.eq_out[p] = a.sc[SC_CN_LAST * st + p];
+  if (a.u_out)
+    for (int kk = 0; kk < a.N; ++kk) a.u_out[(int64_t)kk * ob + p] = zu[(int64_t)kk * st];
+  if (a.pred_out) {
+    const CartPoleConsts<R> k = load_consts(a, p);
+    const ExtForce<R> fe{R(0), R(0), R(0)};
+    R x[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) x[t] = a.x0[t * ob + p];
+    R u_next = zu[0];
+    for (int kk = 0; kk < a.N; ++kk) {
+      const R u = u_next;
+      if (kk + 1 < a.N) u_next = zu[(int64_t)(kk + 1) * st];
+      rk4_step<R, false>(k, a.dt, x, u, fe);
+      x[1] = mod_pi(x[1]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a.pred_out[((int64_t)kk * 4 + t) * ob + p] = x[t];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stand-alone pieces (parity tests, callers that want them)
+// ------------------------------------------------------------------------------------------------
+template <typename R>
+__global__ __launch_bounds__(64) void dynamics_kernel(int64_t B, CartPoleConsts<R> k,
+                                                       ExtForce<R> fe, const R* x, const R* u,
+                                                       R* f, R* Jx, R* Ju) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= B) return;
+  R ax, at, Ja[2][4], Jua[2];
+  const R x0 = x[p], x1 = x[B + p], x2 = x[2 * B + p], x3 = x[3 * B + p];
+  cartpole_accel<R, true, true>(k, x0, x1, x2, x3, u[p], fe, ax, at, Ja, Jua);
+  f[p] = x2;
+  f[B + p] = x3;
+  f[2 * B + p] = ax;
+  f[3 * B + p] = at;
+  if (Jx) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      Jx[(0 * 4 + c) * B + p] = (c == 2) ? R(1) : R(0);
+      Jx[(1 * 4 + c) * B + p] = (c == 3) ? R(1) : R(0);
+      Jx[(2 * 4 + c) * B + p] = Ja[0][c];
+      Jx[(3 * 4 + c) * B + p] = Ja[1][c];
+    }
+  }
+  if (Ju) {
+    Ju[p] = R(0);
+    Ju[B + p] = R(0);
+    Ju[2 * B + p] = Jua[0];
+    Ju[3 * B + p] = Jua[1];
+  }
+}
+
+template <typename R>
+__global__ __launch_bounds__(64) void rk4_kernel(int64_t B, CartPoleConsts<R> k, ExtForce<R> fe,
+                                                  R h, const R* x, const R* u, R* xn, R* A, R* Bm) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= B) return;
+  R xs[4] = {x[p], x[B + p], x[2 * B + p], x[3 * B + p]};
+  if (A != nullptr || Bm != nullptr) {
+    R Am[4][4], Bv[4];
+    rk4_step_jac<R, true>(k, h, xs, u[p], fe, Am, Bv);
+    if (A)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) A[(r * 4 + c) * B + p] = Am[r][c];
+    if (Bm)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Bm[r * B + p] = Bv[r];
+  } else {
+    rk4_step<R, true>(k, h, xs, u[p], fe);
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) xn[t * B + p] = xs[t];
+}
+
+// Simulator::Step (simulator.cc:11-36): fixed 1 ms sub-steps, angle wrapped after each.
+template <typename R>
+__global__ __launch_bounds__(64) void sim_kernel(int64_t B, CartPoleConsts<R> k, ExtForce<R> fe_shared,
+                                                  const R* fext, int n_sub, R h_last, const R* u,
+                                                  R* state) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= B) return;
+  ExtForce<R> fe = fe_shared;
+  if (fext) {
+    fe.fbx = fext[p];
+    fe.fmx = fext[2 * B + p];
+    fe.fmy = fext[3 * B + p];
+  }
+  R xs[4] = {state[p], state[B + p], state[2 * B + p], state[3 * B + p]};
+  const R uu = u[p];
+  // the host evaluates the reference's `while (dt > 0) { SubStep(min(dt, 0.001)); dt -= 0.001; }`
+  // in double and passes the count and the last step, so f32 and f64 take the same sub-steps
+  const R internal_dt = R(0.001);
+  for (int i = 0; i < n_sub; ++i) {
+    const R h = (i + 1 == n_sub) ? h_last : internal_dt;
+    rk4_step<R, true>(k, h, xs, uu, fe);
+    xs[1] = mod_pi(xs[1]);
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) state[t * B + p] = xs[t];
+}
+
+}  // namespace cpmpc

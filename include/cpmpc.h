@@ -1,0 +1,220 @@
+/*
+ * cpmpc.h -- C-ABI of the MI355X-native batched cart-pole MPC hot path (libcpmpc.so).
+ *
+ * The reference (gareth-cross/cart-pole-mpc) has NO plugin/FFI boundary for this path: the hot
+ * path is the C++ class API
+ *     pendulum::Optimization   optimization/optimization.hpp:73-108
+ *     pendulum::Simulator      optimization/simulator.hpp:10-29
+ * linked statically into the nanobind module `pypendulum` (wrapper/wrapper.cc:40-102).  This header
+ * is the boundary a maintainer would bind instead: plain pointers and sizes, int return codes, no
+ * exceptions, caller owns every buffer, the handle owns the device-resident warm-start state
+ * (the batched counterpart of Optimization::previous_solution_, optimization.hpp:107).
+ * Each entry point names the reference interface it replaces.
+ *
+ * Data layout: every batched array is structure-of-arrays, [field][B] with the batch index
+ * fastest, in the handle's dtype (float or double), in DEVICE memory unless the name ends in
+ * `_host`.  Variable layout of the solution vector z follows MapKey (optimization.cc:27-37):
+ *     z[4*s + t]  state t of shooting node s   (t: 0=b_x 1=th_1 2=b_x_dot 3=th_1_dot; key.hpp:8-19)
+ *     z[4*S + k]  control u_k                  (S = window_length/state_spacing + 1, k < N)
+ */
+#ifndef CPMPC_H
+#define CPMPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CPMPC_STATE_DIM 4
+#define CPMPC_NUM_DYN_PARAMS 9
+
+/* ---- return codes ---------------------------------------------------------------------------- */
+enum {
+  CPMPC_OK = 0,
+  CPMPC_ERR_INVALID_ARG = 1,  /* violates a precondition the reference asserts (F_ASSERT*) */
+  CPMPC_ERR_UNSUPPORTED = 2,  /* valid in the reference but not built into this library */
+  CPMPC_ERR_NO_DEVICE = 3,    /* no HIP device / wrong architecture: there is NO CPU fallback */
+  CPMPC_ERR_HIP = 4,          /* a HIP runtime call failed; see cpmpc_last_error() */
+  CPMPC_ERR_ALLOC = 5,
+  CPMPC_ERR_BATCH = 6         /* B exceeds the capacity given to cpmpc_create */
+};
+
+enum { CPMPC_F32 = 0, CPMPC_F64 = 1 };
+
+/* Per-problem termination state, written to `status`.  Names and meaning follow
+ * mini_opt::NLSTerminationState as the reference uses it (optimization_test.cc:44-46). */
+enum {
+  CPMPC_TERM_NONE = 0,
+  CPMPC_TERM_MAX_ITERATIONS = 1,
+  CPMPC_TERM_SATISFIED_ABSOLUTE_TOL = 2,
+  CPMPC_TERM_SATISFIED_RELATIVE_TOL = 3,
+  CPMPC_TERM_SATISFIED_FIRST_ORDER_TOL = 4,
+  CPMPC_TERM_QP_INDEFINITE = 5,
+  CPMPC_TERM_USER_CALLBACK = 6,
+  CPMPC_TERM_MAX_LAMBDA = 7,
+  CPMPC_TERM_NON_FINITE = 8
+};
+
+/* ---- parameters ------------------------------------------------------------------------------ */
+
+/* pendulum::OptimizationParams, field for field (optimization/optimization.hpp:12-53). */
+typedef struct cpmpc_params {
+  double control_dt;
+  uint64_t window_length;
+  uint64_t state_spacing;
+  uint64_t max_iterations;
+  double relative_exit_tol;
+  double absolute_first_derivative_tol;
+  double equality_penalty_initial;
+  double u_guess_sinusoid_amplitude;
+  double u_cost_weight;
+  double u_derivative_cost_weight;
+  double b_x_final_cost_weight;
+  double th_final_cost_weight;
+  double b_x_dot_final_cost_weight;
+  double th_dot_final_cost_weight;
+} cpmpc_params;
+
+/* Knobs of the SQP that stands where mini_opt::ConstrainedNonlinearLeastSquares stands
+ * (optimization.cc:73-81).  Only max_line_search_iterations (=5, optimization.cc:76) and the two
+ * clamps (optimization.cc:320,327) come from the reference; see DESIGN.md section 4. */
+typedef struct cpmpc_solver_opts {
+  int32_t max_line_search_iterations;
+  double armijo_c1;
+  double ls_shrink_max;
+  double ls_shrink_min;
+  double penalty_rho;
+  double lambda_initial;
+  double lambda_failure_init;
+  double lambda_scale_up;
+  double lambda_scale_down;
+  double lambda_min;
+  double lambda_max;
+  double b_x_limit;
+  double u_limit;
+} cpmpc_solver_opts;
+
+void cpmpc_default_params(cpmpc_params* p);           /* optimization.hpp:12-48 defaults */
+void cpmpc_default_solver_opts(cpmpc_solver_opts* o); /* DESIGN.md section 4 defaults */
+
+/* Thread-local text of the last failure on this thread. */
+const char* cpmpc_last_error(void);
+
+/* Number of usable gfx950 devices (0 if none); does not create a context. */
+int cpmpc_device_count(void);
+
+/* ---- the solver handle: replaces `pendulum::Optimization` ---------------------------------- */
+
+typedef struct cpmpc_solver cpmpc_solver;
+
+/* Replaces Optimization::Optimization(const OptimizationParams&) (optimization.cc:13-22), for a
+ * batch of up to `max_batch` independent controllers on HIP device `device`.  The reference's
+ * constructor preconditions give CPMPC_ERR_INVALID_ARG.  state_spacing values built into the
+ * library: see cpmpc_supported_state_spacing(). */
+int cpmpc_create(const cpmpc_params* params, const cpmpc_solver_opts* opts /*nullable*/, int dtype,
+                 int64_t max_batch, int device, cpmpc_solver** out);
+void cpmpc_destroy(cpmpc_solver* s);
+
+int cpmpc_supported_state_spacing(int spacing); /* 1 if kernels for it are compiled in */
+
+/* Inputs of one batched re-plan.  Exactly one of dyn_shared_host / dyn must be non-NULL. */
+typedef struct cpmpc_step_inputs {
+  const void* x0;                /* [4][B]  measured states (Step's current_state) */
+  const double* dyn_shared_host; /* HOST [9] SingleCartPoleParams shared by the batch, or NULL */
+  const void* dyn;               /* [9][B]  per-problem SingleCartPoleParams, or NULL */
+  double set_point_shared;       /* b_x_set_point shared by the batch (used if set_point NULL) */
+  const void* set_point;         /* [B]     per-problem b_x_set_point, or NULL */
+} cpmpc_step_inputs;
+
+/* Outputs; every pointer is nullable. */
+typedef struct cpmpc_step_outputs {
+  void* u;             /* [N][B]     OptimizationOutputs::u                (optimization.hpp:66) */
+  void* predicted;     /* [N][4][B]  OptimizationOutputs::predicted_states (optimization.hpp:69) */
+  int32_t* status;     /* [B]        solver_outputs.termination_state */
+  int32_t* iterations; /* [B]        QP solves performed */
+  int32_t* ls_evals;   /* [B]        merit evaluations performed */
+  void* final_cost;    /* [B]        1/2 |r|^2 at the returned solution's last evaluation */
+  void* final_eq_l1;   /* [B]        |c|_1 there */
+  void* guess;         /* [dim][B]   the initial guess handed to the solver */
+} cpmpc_step_outputs;
+
+/* Replaces Optimization::Step (optimization.cc:39-97) for B problems in lock-step.  Warm start
+ * (shift of the previous solution, optimization.cc:50-57) is used when the handle holds one, else
+ * the sinusoid cold start (optimization.cc:58-68).  Asynchronous on `stream` (a hipStream_t, NULL
+ * = the default stream); all pointers must stay valid until the stream reaches this point. */
+int cpmpc_step_batch(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* in,
+                     const cpmpc_step_outputs* out, void* stream);
+
+/* Replaces Optimization::Reset (optimization.hpp:83). */
+int cpmpc_reset(cpmpc_solver* s);
+/* Replaces Optimization::SetPreviousSolution (optimization.hpp:86-89); z is [dim][B]. */
+int cpmpc_set_previous_solution(cpmpc_solver* s, int64_t B, const void* z, void* stream);
+/* Reads the warm-start state (the reference exposes it as OptimizationOutputs::previous_solution
+ * of the NEXT step, optimization.cc:84); z_out is [dim][B]. */
+int cpmpc_get_solution(cpmpc_solver* s, int64_t B, void* z_out, void* stream);
+int cpmpc_has_previous_solution(const cpmpc_solver* s);
+
+int cpmpc_dim(const cpmpc_solver* s);        /* 4*S + N (optimization.cc:204-205) */
+int cpmpc_num_states(const cpmpc_solver* s); /* OptimizationParams::NumStates (optimization.hpp:52) */
+int cpmpc_dtype(const cpmpc_solver* s);
+
+/* Host-pointer convenience used by the C++ facade (cart-pole-mpc_amd/host): same semantics as
+ * cpmpc_step_batch with HOST double arrays in the same SoA layouts; copies in, runs on the GPU,
+ * copies out, synchronises.  There is no CPU compute path behind it. */
+int cpmpc_step_batch_host(cpmpc_solver* s, int64_t B, const double* x0_host,
+                          const double* dyn_shared_host, double set_point, double* u_host,
+                          double* predicted_host, int32_t* status_host, int32_t* iterations_host,
+                          double* final_cost_host, double* final_eq_l1_host);
+int cpmpc_set_previous_solution_host(cpmpc_solver* s, int64_t B, const double* z_host);
+int cpmpc_get_solution_host(cpmpc_solver* s, int64_t B, double* z_host);
+
+/* ---- pieces of the path, exposed for callers and for parity tests ----------------------------- */
+
+/* gen::single_pendulum_dynamics (single_pendulum_dynamics.hpp:13-186), batched.
+ * fext_host = {f_base.x, f_base.y, f_mass.x, f_mass.y} shared, NULL = zero.
+ * f [4][B]; Jx [16][B] row-major 4x4, nullable; Ju [4][B], nullable. */
+int cpmpc_dynamics_batch(int dtype, int64_t B, const double* dyn_shared_host, const void* x,
+                         const void* u, const double* fext_host, void* f, void* Jx, void* Ju,
+                         void* stream);
+
+/* runge_kutta_4th_order<4> (integration.hpp:13-49) when A/Bm are given, else
+ * runge_kutta_4th_order_no_jacobians<4> (integration.hpp:52-62).  A [16][B], Bm [4][B]. */
+int cpmpc_rk4_batch(int dtype, int64_t B, const double* dyn_shared_host, const void* x,
+                    const void* u, double h, const double* fext_host, void* x_new, void* A,
+                    void* Bm, void* stream);
+
+/* The shooting constraints of BuildProblem (optimization.cc:99-160,208-225) linearised at z:
+ * defect c [4*(S-1)][B], Phi [16*(S-1)][B] (row-major 4x4 per interval), Gamma [4*N][B]
+ * (element (r, k) at field 4*k + r).  Runs the same kernel cpmpc_step_batch runs. */
+int cpmpc_linearize_batch(cpmpc_solver* s, int64_t B, const double* dyn_shared_host, const void* z,
+                          void* c, void* Phi, void* Gamma, void* stream);
+
+/* Simulator::Step (simulator.cc:11-36), batched: state [4][B] in/out, u [B];
+ * fext_host shared {f_base.x, f_base.y, f_mass.x, f_mass.y} or NULL; fext [4][B] per-problem or
+ * NULL (takes precedence).  dt < 0 or non-finite -> CPMPC_ERR_INVALID_ARG (simulator.cc:13). */
+int cpmpc_sim_step_batch(int dtype, int64_t B, const double* dyn_shared_host, double dt,
+                         const void* u, const double* fext_host, const void* fext, void* state,
+                         void* stream);
+
+/* ---- measurement ------------------------------------------------------------------------------ */
+
+enum {
+  CPMPC_KERNEL_PREPARE = 0,   /* guess + FillInitialGuess */
+  CPMPC_KERNEL_LINEARIZE = 1, /* RK4 + Jacobians over every shooting interval */
+  CPMPC_KERNEL_QP_LS = 2,     /* structured QP + merit line search */
+  CPMPC_KERNEL_FINALIZE = 3,  /* ComputePredictedStates + outputs */
+  CPMPC_KERNEL_COUNT = 4
+};
+
+/* When enabled, every kernel launch of cpmpc_step_batch is bracketed by HIP events on the launch
+ * stream; cpmpc_profile_read synchronises those events and returns the accumulated device time. */
+int cpmpc_profile_enable(cpmpc_solver* s, int on);
+int cpmpc_profile_reset(cpmpc_solver* s);
+int cpmpc_profile_read(cpmpc_solver* s, int kernel, double* total_ms, int64_t* launches);
+const char* cpmpc_kernel_name(int kernel);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
