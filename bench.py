@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- MPC re-plans/sec of the batched cart-pole MPC hot path on MI355X.
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): batch = 262144
+independent cart-poles per GPU, horizon N = 40, state_spacing = 10, fp32, cold start, exactly 5 SQP
+iterations (exit tolerances disabled so every lane does the full fixed work), seeded random initial
+states, shared dynamics parameters, outputs u [N,B], predicted states
+[N,4,B] and status written.  A "step" = one full batched re-plan (Optimization::Step for every
+problem).  With --gpus N > 1 every rank solves its own 262144 problems (weak scaling, no data-path
+collective) and the control sequences are gathered to rank 0 over RCCL.
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task description).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+DYN_UI = [1.0, 0.1, 0.25, 9.81, 0.05, 0.1, 0.02, 0.8, 100.0]  # viz/src/application.ts:61-71
+
+# Algorithmic work per re-plan and SQP iteration, SURVEY.md section 8(d) (restated in DESIGN.md):
+FLOPS_LINEARIZE = 40 * (1560 + 140)   # 68 k: 40 x (RK4 with Jacobians + chain rule)
+FLOPS_MERIT = 40 * 350                # 14 k: one Jacobian-free rollout
+FLOPS_QP = 30_000                     # structured QP
+FLOPS_PER_LAUNCH_UNIT = {
+    "linearize_kernel": FLOPS_LINEARIZE,
+    "qp_ls_kernel": FLOPS_QP + FLOPS_MERIT,   # nominal: one merit evaluation per iteration
+    "prepare_kernel": FLOPS_MERIT,
+    "finalize_kernel": FLOPS_MERIT,
+}
+PEAK_VALU_TFLOPS = {"f32": 157.3, "f64": 78.6}  # MI355X_MICROARCH.md (vector peak); f64 = public spec
+PEAK_HBM_GBPS = 8000.0
+
+
+def synth_states(seed, B):
+    rng = np.random.default_rng(seed)
+    return np.stack([rng.uniform(-0.6, 0.6, B), rng.uniform(-np.pi, np.pi, B), rng.uniform(-1, 1, B),
+                     rng.uniform(-3, 3, B)])
+
+
+def cpu_baseline(x0_np, over, seconds_target=15.0):
+    """The oracle (CPU restatement, fp64, OpenMP over problems) timed on this host on a bounded sample
+    of the same workload.  Reported baseline only."""
+    from oracle import oracle as orc
+    p = orc.default_opt_params(**over)
+    cores = os.cpu_count() or 1
+    probe = min(max(512, 8 * cores), x0_np.shape[1])
+    t0 = time.perf_counter()
+    _, _, _, _, used = orc.step_batch_cold(p, DYN_UI, 0.0, x0_np[:, :probe], num_threads=cores)
+    rate = probe / max(time.perf_counter() - t0, 1e-6)
+    n = int(min(x0_np.shape[1], max(probe, rate * seconds_target)))
+    t0 = time.perf_counter()
+    u, _, st, _, used = orc.step_batch_cold(p, DYN_UI, 0.0, x0_np[:, :n], num_threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "re-plans/s", "cores": int(used), "kind": "port",
+            "sample": "first %d problems of rank 0's batch, same N=40/5-iteration cold-start workload, fp64, "
+                      "oracle/cpmpc_oracle.c with OpenMP, %.1f s" % (n, dt)}, u, n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=262144, help="problems per GPU")
+    ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    pkg = importlib.import_module("cart-pole-mpc_amd")
+    sharding = importlib.import_module("cart-pole-mpc_amd.sharding")
+    tdt = torch.float32 if args.dtype == "f32" else torch.float64
+    B = args.batch
+    over = dict(max_iterations=args.iters, relative_exit_tol=0.0, absolute_first_derivative_tol=0.0)
+    params = pkg.default_params(**over)
+    N = int(params.window_length)
+
+    x0_np = synth_states(1000 + rank, B)  # rank-specific shard of the global synthetic batch
+    x0 = torch.tensor(x0_np, dtype=tdt, device=dev)
+    opt = pkg.BatchOptimization(params, max_batch=B, dtype=tdt, device=local_rank)
+    outs = [pkg.BatchOutputs(), pkg.BatchOutputs()]
+    gather = None
+    if world > 1 and not args.no_gather:
+        gather = sharding.ResultGather(N, B, tdt, dev, dst=0, depth=2)
+
+    def one_step(i):
+        slot = i % 2
+        if gather is not None:
+            gather.wait_slot(slot)   # the buffer we are about to overwrite has been sent
+        opt.reset()                  # cold start: every step is a full re-plan from the sinusoid guess
+        o = opt.step(x0, DYN_UI, 0.0, want_predicted=True, want_stats=True, out=outs[slot])
+        if gather is not None:
+            gather.submit(o.u)
+        return o
+
+    def fence():
+        if gather is not None:
+            gather.finish()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_step(i)
+    fence()
+    opt.profile_enable(True)
+    opt.profile_reset()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = one_step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    elapsed = sharding.max_over_ranks(elapsed, dev)
+    prof = opt.profile_read()
+    opt.profile_enable(False)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    total_problems = world * B
+    value = total_problems * args.steps / elapsed
+    # dominant kernel by measured device time (HIP events on the launch stream, timed region)
+    dom = max(prof, key=lambda k: prof[k][0])
+    dom_ms, dom_n = prof[dom]
+    avg_s = dom_ms / max(dom_n, 1) * 1e-3
+    flops_launch = FLOPS_PER_LAUNCH_UNIT[dom] * B
+    achieved_tf = flops_launch / avg_s / 1e12
+    peak_tf = PEAK_VALU_TFLOPS[args.dtype]
+    esz = 4 if args.dtype == "f32" else 8
+    bytes_replan = esz * ((4 + 1) + (60 + 160)) + 4   # read x0 + set-point, write z + predicted, status
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("dtype") == args.dtype and tj.get("batch") == B:
+                traffic = tj.get("per_launch_bytes", {}).get(dom)
+        except Exception:
+            traffic = None
+    roofline = {
+        "bound": "valu", "kernel": dom, "achieved": round(achieved_tf, 3), "peak": peak_tf, "unit": "TFLOP/s",
+        "frac": round(achieved_tf / peak_tf, 4), "traffic": traffic,
+        "avg_launch_ms": round(avg_s * 1e3, 4), "launches": int(dom_n),
+        "algorithmic_flops_per_launch": flops_launch,
+        "hbm": {"algorithmic_bytes_per_replan": bytes_replan,
+                "achieved_GBps": round(bytes_replan * value / world / 1e9, 3), "peak_GBps": PEAK_HBM_GBPS,
+                "frac": round(bytes_replan * value / world / 1e9 / PEAK_HBM_GBPS, 6)},
+        "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in prof.items()},
+        "note": "the path is vector-ALU/transcendental bound (SURVEY.md 8d), neither HBM nor MFMA; "
+                "achieved = SURVEY 8(d) algorithmic flops of the dominant kernel / its HIP-event time",
+    }
+    line = {
+        "metric": "MPC re-plans/sec (whole node), N=40 horizon, 5 SQP iters, batch 256k",
+        "value": value, "unit": "re-plans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "BASELINE configs[2]: batch=%d per GPU, N=40, state_spacing=10, %s, cold start, "
+                               "%d SQP iterations (exits disabled), u+predicted+status written%s"
+                               % (B, args.dtype, args.iters, ", u gathered to rank 0 (RCCL)" if gather else ""),
+                   "batch_per_gpu": B, "horizon": N, "sqp_iterations": args.iters,
+                   "parallelism": "dp%d" % world},
+        "roofline": roofline,
+    }
+    st = out.status.cpu().numpy()
+    line["status_histogram"] = {pkg.capi.TERM_NAMES[int(c)]: int((st == c).sum()) for c in np.unique(st)}
+    line["mean_merit_evals_per_iter"] = float(out.ls_evals.float().mean().item() / args.iters)
+    if not args.no_cpu_baseline and world == 1:
+        base, u_cpu, n = cpu_baseline(x0_np, over)
+        line["cpu_baseline"] = base
+        err = np.abs(out.u[:, :n].double().cpu().numpy() - u_cpu).max(axis=0)
+        line["parity_sample"] = {"lanes": int(n), "max_abs_du_median": float(np.median(err)),
+                                 "max_abs_du_p99": float(np.quantile(err, 0.99)), "max_abs_du_max": float(err.max()),
+                                 "note": "GPU %s vs fp64 oracle on the cpu_baseline sample" % args.dtype}
+        line["gpu_over_cpu"] = value / base["value"]
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -294,8 +294,11 @@ class Optimization:
         self._prev = None
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().orc_opt_destroy(self._h)
+        if getattr(self, "_h", None) and _lib is not None:
+            try:
+                _lib.orc_opt_destroy(self._h)
+            except Exception:
+                pass
             self._h = None
 
     def reset(self):

@@ -1,0 +1,107 @@
+"""The C-ABI library loads, exports every symbol include/cpmpc.h declares, mirrors the reference's
+parameter struct and fails loudly without a GPU.  No compute calls (CPU only)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def lib(pkg):
+    import __graft_entry__
+    __graft_entry__.build()
+    return pkg.capi.load()
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "cpmpc.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cpmpc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(lib, pkg):
+    declared = _declared_functions()
+    assert len(declared) >= 25
+    assert sorted(pkg.capi.SYMBOLS) == declared
+    raw = C.CDLL(pkg.capi.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), name
+
+
+def test_params_mirror_reference_defaults(lib, pkg, orc):
+    """optimization/optimization.hpp:12-48, field for field, and equal to the oracle's mirror."""
+    p = pkg.default_params()
+    want = dict(control_dt=0.01, window_length=40, state_spacing=10, max_iterations=8,
+                relative_exit_tol=1.0e-5, absolute_first_derivative_tol=1.0e-6,
+                equality_penalty_initial=1.0, u_guess_sinusoid_amplitude=10.0, u_cost_weight=0.1,
+                u_derivative_cost_weight=0.1, b_x_final_cost_weight=150.0, th_final_cost_weight=-1.0,
+                b_x_dot_final_cost_weight=-1.0, th_dot_final_cost_weight=-1.0)
+    assert [f for f, _ in p._fields_] == list(want)
+    op = orc.default_opt_params()
+    for k, v in want.items():
+        assert getattr(p, k) == v and getattr(op, k) == v
+    assert C.sizeof(p) == 14 * 8
+    o, oo = pkg.default_solver_opts(), orc.default_solver_opts()
+    assert [f for f, _ in o._fields_] == [f for f, _ in oo._fields_]
+    for f, _ in o._fields_:
+        assert getattr(o, f) == getattr(oo, f), f
+    assert o.max_line_search_iterations == 5  # optimization.cc:76
+
+
+def test_supported_spacings(lib):
+    for sp in (1, 2, 4, 5, 8, 10, 20):
+        assert lib.cpmpc_supported_state_spacing(sp) == 1
+    assert lib.cpmpc_supported_state_spacing(3) == 0
+
+
+def test_kernel_names(lib, pkg):
+    names = [lib.cpmpc_kernel_name(i).decode() for i in range(pkg.capi.KERNEL_COUNT)]
+    assert names == ["prepare_kernel", "linearize_kernel", "qp_ls_kernel", "finalize_kernel"]
+
+
+def test_create_validates_like_the_reference_constructor(lib, pkg):
+    """optimization.cc:13-22 preconditions -> CPMPC_ERR_INVALID_ARG, before any device is touched."""
+    h = C.c_void_p()
+    for bad in (dict(control_dt=0.0), dict(window_length=0), dict(state_spacing=7),
+                dict(max_iterations=0), dict(u_cost_weight=-1.0), dict(u_derivative_cost_weight=-1.0)):
+        p = pkg.default_params(**bad)
+        rc = lib.cpmpc_create(C.byref(p), None, pkg.capi.F32, 64, 0, C.byref(h))
+        assert rc == pkg.capi.ERR_INVALID_ARG, bad
+        assert lib.cpmpc_last_error()
+    p = pkg.default_params(state_spacing=40)  # valid in the reference, no kernel built for it
+    assert lib.cpmpc_create(C.byref(p), None, pkg.capi.F32, 64, 0, C.byref(h)) == pkg.capi.ERR_UNSUPPORTED
+    p = pkg.default_params()
+    assert lib.cpmpc_create(C.byref(p), None, 7, 64, 0, C.byref(h)) == pkg.capi.ERR_INVALID_ARG
+    assert lib.cpmpc_create(C.byref(p), None, pkg.capi.F32, 0, 0, C.byref(h)) == pkg.capi.ERR_INVALID_ARG
+
+
+def test_fails_loudly_without_a_gpu(lib, pkg):
+    """No CPU fallback: with no gfx950 device every compute entry point reports CPMPC_ERR_NO_DEVICE."""
+    if lib.cpmpc_device_count() > 0:
+        pytest.skip("a GPU is present")
+    h = C.c_void_p()
+    p = pkg.default_params()
+    rc = lib.cpmpc_create(C.byref(p), None, pkg.capi.F64, 64, 0, C.byref(h))
+    assert rc == pkg.capi.ERR_NO_DEVICE
+    assert b"no CPU fallback" in lib.cpmpc_last_error() or b"not gfx950" in lib.cpmpc_last_error()
+    dyn = pkg.capi.dbl_array([1.0, 0.1, 0.25, 9.81, 0.05, 0.1, 0.02, 0.8, 100.0], 9)
+    one = C.c_void_p(8)  # never dereferenced: the device check comes first
+    assert lib.cpmpc_rk4_batch(pkg.capi.F64, 1, dyn, one, one, 0.01, None, one, None, None,
+                               None) == pkg.capi.ERR_NO_DEVICE
+    assert lib.cpmpc_sim_step_batch(pkg.capi.F64, 1, dyn, 0.01, one, None, None, one,
+                                    None) == pkg.capi.ERR_NO_DEVICE
+    with pytest.raises(pkg.CpmpcError):
+        pkg.capi.check(rc)
+
+
+def test_product_does_not_import_the_oracle():
+    """The product package must never route through oracle/ (or any CPU fallback)."""
+    pkg_dir = os.path.join(ROOT, "cart-pole-mpc_amd")
+    for base, _, files in os.walk(pkg_dir):
+        for name in files:
+            if name.endswith((".py", ".hip", ".hpp", ".h", ".cc", ".cpp")):
+                text = open(os.path.join(base, name), errors="replace").read()
+                assert "oracle" not in text.lower().replace("no cpu fallback", ""), os.path.join(base, name)

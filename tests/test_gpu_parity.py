@@ -1,0 +1,426 @@
+"""GPU parity tests: the HIP path, called through the C-ABI (libcpmpc.so), against the CPU oracle on
+the same seeded inputs, against the committed golden fixtures, and -- at BASELINE.json's full sizes
+-- through size-independent properties.
+
+Tolerances: fp64 control sequences within 1e-5 of the oracle (BASELINE.json north_star); building
+blocks to ~1e-12.  fp32 is reported and loosely bounded (the reference is fp64-only)."""
+import numpy as np
+import pytest
+
+from conftest import DYN_DERIV, DYN_TEST, DYN_UI, random_states
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+DEV = "cuda:0"
+NO_TOL = dict(max_iterations=5, relative_exit_tol=0.0, absolute_first_derivative_tol=0.0)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu(pkg):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU: the product has no CPU fallback")
+    pkg.capi.load()
+    assert pkg.capi.load().cpmpc_device_count() >= 1
+
+
+def T(a, dtype=torch.float64):
+    return torch.tensor(np.ascontiguousarray(a), dtype=dtype, device=DEV)
+
+
+def N_(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------
+# a1-a4: dynamics, RK4, mod_pi
+# ------------------------------------------------------------------------------------------------
+def test_dynamics_golden_vectors(pkg, golden_dynamics):
+    """Every golden case (independent SymPy derivation) through cpmpc_dynamics_batch, fp64."""
+    for c in golden_dynamics:
+        x = T(np.array(c["x"]).reshape(4, 1))
+        u = T([c["u"]])
+        f, Jx, Ju = pkg.dynamics_batch(c["params"], x, u, fext=c["f_base"] + c["f_mass"])
+        for got, want in ((N_(f)[:, 0], c["f"]), (N_(Jx)[:, :, 0], c["J_x"]), (N_(Ju)[:, 0], c["J_u"])):
+            want = np.asarray(want)
+            assert np.abs(got - want).max() / max(1.0, np.abs(want).max()) < 1e-12, c["tag"]
+
+
+def test_survey_known_answers(pkg, survey_answers):
+    k = survey_answers
+    x, u = T(np.array(k["x"]).reshape(4, 1)), T([k["u"]])
+    f, Jx, Ju = pkg.dynamics_batch(k["params"], x, u)
+    np.testing.assert_allclose(N_(f)[:, 0], k["f"], rtol=0, atol=5e-14)
+    np.testing.assert_allclose(N_(Jx)[2, :, 0], k["J_x_row2"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(N_(Jx)[3, :, 0], k["J_x_row3"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(N_(Ju)[:, 0], k["J_u"], rtol=0, atol=1e-14)
+    xn, A, B = pkg.rk4_batch(k["params"], x, u, k["dt"])
+    np.testing.assert_allclose(N_(xn)[:, 0], k["rk4_x_new"], rtol=0, atol=2e-15)
+    np.testing.assert_allclose(N_(A)[0, :, 0], k["rk4_A_row0"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(N_(B)[:, 0], k["rk4_B"], rtol=0, atol=1e-15)
+
+
+@pytest.mark.parametrize("ext", [False, True])
+def test_rk4_matches_oracle(pkg, orc, ext):
+    rng = np.random.default_rng(7)
+    B = 300  # ragged: not a multiple of the 64-lane wave
+    x = np.stack([rng.uniform(-1.5, 1.5, B), rng.uniform(-4, 4, B), rng.uniform(-2, 2, B), rng.uniform(-6, 6, B)])
+    u = rng.uniform(-50, 50, B)
+    fext = [1.5, -0.7, 0.4, -0.9] if ext else None
+    xn, A, Bm = pkg.rk4_batch(DYN_UI, T(x), T(u), 0.01, fext=fext)
+    xn2 = pkg.rk4_batch(DYN_UI, T(x), T(u), 0.01, fext=fext, jacobians=False)
+    xn, A, Bm, xn2 = N_(xn), N_(A), N_(Bm), N_(xn2)
+    for b in range(B):
+        fb, fm = (fext[:2], fext[2:]) if ext else (None, None)
+        xo, Ao, Bo = orc.rk4(DYN_UI, x[:, b], u[b], 0.01, fb, fm)
+        np.testing.assert_allclose(xn[:, b], xo, rtol=0, atol=1e-13)
+        np.testing.assert_allclose(xn2[:, b], xo, rtol=0, atol=1e-13)
+        np.testing.assert_allclose(A[:, :, b], Ao, rtol=0, atol=1e-13)
+        np.testing.assert_allclose(Bm[:, b], Bo, rtol=0, atol=1e-14)
+
+
+def test_rk4_derivatives_like_reference(pkg):
+    """IntegrationTest.TestDerivatives (integration_test.cc:45-80) on the GPU path itself: analytic
+    A, B against the 6th-order stencil applied to the GPU's Jacobian-free RK4."""
+    x0 = np.array([1.2, 0.7, 0.4, -0.15])
+    u0, dt, h = 0.1, 0.01, 0.01
+    _, A, Bm = pkg.rk4_batch(DYN_DERIV, T(x0.reshape(4, 1)), T([u0]), dt)
+    offs = np.array([-3, -2, -1, 1, 2, 3]) * h
+    coef = np.array([-1, 9, -45, 45, -9, 1]) / (60 * h)
+    cols = []
+    for j in range(4):
+        X = np.repeat(x0.reshape(4, 1), 6, axis=1)
+        X[j] += offs
+        Y = N_(pkg.rk4_batch(DYN_DERIV, T(X), T(np.full(6, u0)), dt, jacobians=False))
+        cols.append(Y @ coef)
+    A_num = np.stack(cols, axis=1)
+    Y = N_(pkg.rk4_batch(DYN_DERIV, T(np.repeat(x0.reshape(4, 1), 6, axis=1)), T(u0 + offs), dt, jacobians=False))
+    B_num = Y @ coef
+    assert np.linalg.norm(N_(A)[:, :, 0] - A_num) < 1.0e-12
+    assert np.linalg.norm(N_(Bm)[:, 0] - B_num) < 1.0e-12
+
+
+def test_simulator_matches_oracle(pkg, orc):
+    """Simulator::Step (simulator.cc:11-36) batched, with per-problem external forces."""
+    rng = np.random.default_rng(9)
+    B = 130
+    sim = pkg.BatchSimulator(B, dtype=torch.float64, device=0)
+    np.testing.assert_array_equal(N_(sim.get_state())[:, 0], [0.0, -np.pi / 2, 0.0, 0.0])  # simulator.hpp:28
+    st = random_states(rng, B)
+    st[1] = rng.uniform(2.9, 3.14, B)  # near the wrap
+    st[3] = rng.uniform(2, 6, B)
+    u = rng.uniform(-20, 20, B)
+    fext = rng.uniform(-3, 3, (4, B))
+    sim.set_state(T(st))
+    for dt in (0.01, 0.0025):
+        sim.step(DYN_TEST, dt, T(u), fext=T(fext))
+    got = N_(sim.get_state())
+    for b in range(B):
+        o = orc.Simulator()
+        o.set_state(st[:, b])
+        for dt in (0.01, 0.0025):
+            o.step(DYN_TEST, dt, u[b], fext[:2, b], fext[2:, b])
+        np.testing.assert_allclose(got[:, b], o.get_state(), rtol=0, atol=1e-12)
+    # shared forces path and dt = 0 (no-op)
+    sim.set_state(T(st))
+    sim.step(DYN_TEST, 0.0, T(u))
+    np.testing.assert_array_equal(N_(sim.get_state()), st)
+    sim.step(DYN_TEST, 0.003, T(u), f_base=(2.0, 0.0), f_mass=(0.0, -1.0))
+    o = orc.Simulator()
+    o.set_state(st[:, 5])
+    o.step(DYN_TEST, 0.003, u[5], (2.0, 0.0), (0.0, -1.0))
+    np.testing.assert_allclose(N_(sim.get_state())[:, 5], o.get_state(), rtol=0, atol=1e-12)
+    with pytest.raises(pkg.CpmpcError):  # simulator.cc:13
+        sim.step(DYN_TEST, -0.01, T(u))
+
+
+# ------------------------------------------------------------------------------------------------
+# a5: shooting constraints + chain rule
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,sp", [(40, 10), (40, 5), (20, 10), (40, 20), (8, 1), (8, 2), (16, 4), (16, 8)])
+def test_linearize_matches_oracle(pkg, orc, N, sp):
+    S = N // sp + 1
+    rng = np.random.default_rng(N * 100 + sp)
+    B = 70
+    p = pkg.default_params(window_length=N, state_spacing=sp)
+    opt = pkg.BatchOptimization(p, max_batch=B, dtype=torch.float64, device=0)
+    z = np.concatenate([np.tile(random_states(rng, B), (S, 1)) + rng.normal(0, 0.05, (4 * S, B)),
+                        rng.uniform(-30, 30, (N, B))])
+    z[1::4][:S] += rng.uniform(-0.3, 0.3, (S, B))
+    c, Phi, Gam = opt.linearize(T(z), DYN_UI)
+    c, Phi, Gam = N_(c), N_(Phi), N_(Gam)
+    for b in range(0, B, 3):
+        for s in range(S - 1):
+            vars_ = np.concatenate([z[4 * s:4 * s + 4, b], z[4 * (s + 1):4 * (s + 1) + 4, b],
+                                    z[4 * S + s * sp:4 * S + (s + 1) * sp, b]])
+            err, J = orc.shooting_constraint(DYN_UI, sp, 0.01, vars_)
+            np.testing.assert_allclose(c[4 * s:4 * s + 4, b], err, rtol=0, atol=1e-12)
+            np.testing.assert_allclose(Phi[s, :, :, b], J[:, :4], rtol=0, atol=1e-12)
+            np.testing.assert_allclose(Gam[s * sp:(s + 1) * sp, :, b].T, J[:, 8:], rtol=0, atol=1e-12)
+
+
+# ------------------------------------------------------------------------------------------------
+# a6-a9: the full re-plan
+# ------------------------------------------------------------------------------------------------
+def _compare_step(pkg, orc, over, x0, dyn=DYN_UI, set_point=0.0, tol=1e-5):
+    B = x0.shape[1]
+    opt = pkg.BatchOptimization(pkg.default_params(**over), max_batch=B, dtype=torch.float64, device=0)
+    out = opt.step(T(x0), dyn, set_point, want_guess=True)
+    torch.cuda.synchronize()
+    u_cpu, pred_cpu, st_cpu, it_cpu, _ = orc.step_batch_cold(orc.default_opt_params(**over), dyn, set_point, x0,
+                                                             want_pred=True)
+    err = np.abs(N_(out.u) - u_cpu).max(axis=0)
+    perr = np.abs(N_(out.predicted_states) - pred_cpu).max(axis=(0, 1))
+    return out, err, perr, N_(out.status) == st_cpu, N_(out.iterations) == it_cpu
+
+
+def test_step_parity_config2(pkg, orc):
+    """BASELINE.json configs[1]: batch=4096 random initial states, N=40, fp64, 5 SQP iterations, exits
+    disabled.  Control sequence within 1e-5 of the oracle on every lane."""
+    rng = np.random.default_rng(0)
+    x0 = random_states(rng, 4096)
+    out, err, perr, st_ok, it_ok = _compare_step(pkg, orc, NO_TOL, x0)
+    print("config2: |du| median %.2e p99 %.2e max %.2e; pred max %.2e" % (
+        np.median(err), np.quantile(err, 0.99), err.max(), perr.max()))
+    assert st_ok.all() and it_ok.all()
+    assert err.max() < 1e-5
+    assert perr.max() < 1e-5
+    assert (N_(out.iterations) == 5).all()
+
+
+def test_step_parity_default_exits(pkg, orc):
+    """Reference defaults (8 iterations, exits enabled, optimization.hpp:12-48): same termination state,
+    same iteration count, same controls."""
+    rng = np.random.default_rng(1)
+    x0 = random_states(rng, 1000)
+    x0[1, :500] = np.pi / 2 + rng.uniform(-0.4, 0.4, 500)  # half near upright: these converge and exit
+    out, err, perr, st_ok, it_ok = _compare_step(pkg, orc, {}, x0)
+    st = N_(out.status)
+    assert len(set(st.tolist())) >= 2, "expected a mix of termination states"
+    assert st_ok.mean() > 0.995 and it_ok.mean() > 0.995
+    good = st_ok & it_ok
+    assert err[good].max() < 1e-5
+
+
+@pytest.mark.parametrize("over", [
+    dict(window_length=40, state_spacing=5, max_iterations=6),                        # optimization_test.cc:13-19
+    dict(window_length=20, state_spacing=10, max_iterations=6),                       # BASELINE config 1 shape
+    dict(window_length=20, state_spacing=5, max_iterations=4),
+    dict(window_length=40, state_spacing=20, max_iterations=4),
+    dict(window_length=16, state_spacing=8, max_iterations=4),
+    dict(window_length=8, state_spacing=1, max_iterations=4),                         # pure multiple shooting
+    dict(max_iterations=30, u_cost_weight=0.0, b_x_final_cost_weight=5.0, absolute_first_derivative_tol=1e-3,
+         b_x_dot_final_cost_weight=100.0, th_dot_final_cost_weight=100.0),            # model/scratch.py:26-36
+    dict(max_iterations=5, th_final_cost_weight=50.0, b_x_dot_final_cost_weight=0.0,
+         th_dot_final_cost_weight=3.0),                                               # every terminal row a cost
+    dict(max_iterations=5, b_x_final_cost_weight=-1.0),                               # every terminal row an equality
+    dict(max_iterations=5, u_derivative_cost_weight=0.0),                             # no du rows
+    dict(max_iterations=5, control_dt=0.02, u_guess_sinusoid_amplitude=3.0, equality_penalty_initial=10.0),
+])
+def test_step_parity_configurations(pkg, orc, over):
+    rng = np.random.default_rng(42)
+    x0 = random_states(rng, 192)
+    x0[1, ::2] = np.pi / 2 + rng.uniform(-0.5, 0.5, 96)
+    out, err, perr, st_ok, it_ok = _compare_step(pkg, orc, over, x0, dyn=DYN_TEST, set_point=0.1)
+    good = st_ok & it_ok
+    assert good.mean() > 0.98
+    # Lanes that converge must agree to 1e-5.  A lane that is still far from feasible after the last
+    # iteration is an expansive fixed-point iteration (rounding differences grow ~30x per SQP iteration,
+    # measured), so over long runs a small fraction of such lanes may drift apart: bound that fraction.
+    converged = good & (N_(out.final_eq_l1) < 1e-4)
+    assert converged.sum() >= 20
+    assert err[converged].max() < 1e-5, np.sort(err[converged])[-5:]
+    assert perr[converged].max() < 1e-5
+    assert (err[good] < 1e-5).mean() >= 0.99, np.sort(err[good])[-5:]
+
+
+def test_edge_batches(pkg, orc):
+    """B = 1, a ragged B, capacity errors, and the reference's scratch.py call sequence at B = 1."""
+    rng = np.random.default_rng(3)
+    for B in (1, 65, 127):
+        x0 = random_states(rng, B)
+        out, err, perr, st_ok, it_ok = _compare_step(pkg, orc, NO_TOL, x0)
+        assert st_ok.all() and err.max() < 1e-5
+    opt = pkg.BatchOptimization(pkg.default_params(), max_batch=64, dtype=torch.float64, device=0)
+    with pytest.raises(pkg.CpmpcError) as ei:
+        opt.step(T(random_states(rng, 65)), DYN_UI, 0.0)
+    assert ei.value.code == pkg.capi.ERR_BATCH
+    with pytest.raises(pkg.CpmpcError):
+        opt.step(T(random_states(rng, 4)), DYN_UI, float("nan"))
+    with pytest.raises(TypeError):
+        opt.step(T(random_states(rng, 4), torch.float32), DYN_UI, 0.0)
+
+
+def test_per_problem_parameters_and_set_points(pkg, orc):
+    """Heterogeneous SingleCartPoleParams [9,B] and set-points [B]."""
+    rng = np.random.default_rng(5)
+    B = 96
+    x0 = random_states(rng, B)
+    x0[1] = np.pi / 2 + rng.uniform(-0.5, 0.5, B)
+    dyn = np.tile(np.array(DYN_UI).reshape(9, 1), (1, B))
+    dyn[0] *= rng.uniform(0.7, 1.3, B)
+    dyn[1] *= rng.uniform(0.7, 1.3, B)
+    dyn[2] *= rng.uniform(0.8, 1.2, B)
+    dyn[4] = rng.uniform(0.0, 0.2, B)
+    dyn[6] = rng.uniform(0.0, 0.3, B)
+    sp = rng.uniform(-0.3, 0.3, B)
+    over = dict(max_iterations=6)
+    opt = pkg.BatchOptimization(pkg.default_params(**over), max_batch=B, dtype=torch.float64, device=0)
+    out = opt.step(T(x0), T(dyn), T(sp))
+    u = N_(out.u)
+    p = orc.default_opt_params(**over)
+    for b in range(B):
+        o = orc.Optimization(p).step(x0[:, b], dyn[:, b], sp[b])
+        assert N_(out.status)[b] == o.solver_outputs.termination_state
+        np.testing.assert_allclose(u[:, b], o.u, rtol=0, atol=1e-5)
+
+
+def test_warm_start_closed_loop(pkg, orc):
+    """Optimization::Step over consecutive ticks with the plant in the loop (optimization_test.cc:39-61),
+    64 controllers at once: warm-start shift, u_prev bookkeeping and Simulator all on the GPU, compared
+    tick by tick with 64 oracle controllers."""
+    rng = np.random.default_rng(8)
+    B, ticks = 64, 25
+    x0 = random_states(rng, B)
+    x0[1] = np.pi / 2 + rng.uniform(-0.6, 0.6, B)
+    over = dict(state_spacing=5, max_iterations=10)
+    opt = pkg.BatchOptimization(pkg.default_params(**over), max_batch=B, dtype=torch.float64, device=0)
+    sim = pkg.BatchSimulator(B, dtype=torch.float64, device=0)
+    sim.set_state(T(x0))
+    p = orc.default_opt_params(**over)
+    o_opt = [orc.Optimization(p) for _ in range(B)]
+    o_sim = [orc.Simulator() for _ in range(B)]
+    for b in range(B):
+        o_sim[b].set_state(x0[:, b])
+    assert not opt.has_previous_solution()
+    worst = 0.0
+    for t in range(ticks):
+        out = opt.step(sim.get_state().clone(), DYN_TEST, 0.0)
+        u0 = out.u[0].contiguous()
+        sim.step(DYN_TEST, 0.01, u0)
+        u_gpu, st_gpu = N_(out.u), N_(out.status)
+        for b in range(B):
+            o = o_opt[b].step(o_sim[b].get_state(), DYN_TEST, 0.0)
+            o_sim[b].step(DYN_TEST, 0.01, o.u[0])
+            assert st_gpu[b] == o.solver_outputs.termination_state, (t, b)
+            worst = max(worst, np.abs(u_gpu[:, b] - o.u).max())
+    assert opt.has_previous_solution()
+    assert worst < 1e-5
+    state = N_(sim.get_state())
+    for b in range(B):
+        np.testing.assert_allclose(state[:, b], o_sim[b].get_state(), rtol=0, atol=1e-6)
+
+
+def test_reset_and_set_previous_solution(pkg, orc):
+    """Optimization::Reset / SetPreviousSolution (optimization.hpp:83-89)."""
+    rng = np.random.default_rng(12)
+    B = 80
+    x0, x1 = random_states(rng, B), random_states(rng, B)
+    over = dict(max_iterations=3)
+    opt = pkg.BatchOptimization(pkg.default_params(**over), max_batch=128, dtype=torch.float64, device=0)
+    out1 = opt.step(T(x0), DYN_UI, 0.0)
+    u1 = out1.u.clone()
+    z1 = opt.get_solution(B)
+    out2 = opt.step(T(x1), DYN_UI, 0.0, want_guess=True)
+    u2, g2 = out2.u.clone(), out2.guess.clone()
+    S, N = 5, 40
+    assert torch.equal(g2[4 * S:4 * S + N - 1], z1[4 * S + 1:])  # shift left (optimization.cc:54-57)
+    assert torch.equal(g2[-1], z1[-1]) and torch.equal(g2[:4], T(x1))
+    opt.reset()
+    assert not opt.has_previous_solution()
+    assert torch.equal(opt.step(T(x0), DYN_UI, 0.0).u, u1)
+    opt.reset()
+    opt.set_previous_solution(z1)
+    assert torch.equal(opt.step(T(x1), DYN_UI, 0.0).u, u2)
+    o = orc.Optimization(orc.default_opt_params(**over))
+    o.step(x0[:, 7], DYN_UI, 0.0)
+    np.testing.assert_allclose(N_(u2)[:, 7], o.step(x1[:, 7], DYN_UI, 0.0).u, rtol=0, atol=1e-5)
+
+
+def test_non_finite_lane_does_not_poison_neighbours(pkg):
+    rng = np.random.default_rng(13)
+    B = 128
+    x0 = random_states(rng, B)
+    opt = pkg.BatchOptimization(pkg.default_params(**NO_TOL), max_batch=B, dtype=torch.float64, device=0)
+    clean = opt.step(T(x0), DYN_UI, 0.0).u.clone()
+    bad = x0.copy()
+    bad[2, 17] = np.nan
+    bad[0, 64] = np.inf
+    opt.reset()
+    out = opt.step(T(bad), DYN_UI, 0.0)
+    st = N_(out.status)
+    assert st[17] == pkg.capi.TERM["NON_FINITE"] and st[64] == pkg.capi.TERM["NON_FINITE"]
+    keep = np.ones(B, bool)
+    keep[[17, 64]] = False
+    assert torch.equal(out.u[:, T(keep, torch.bool)], clean[:, T(keep, torch.bool)])
+
+
+# ------------------------------------------------------------------------------------------------
+# full-size properties (BASELINE.json configs[2]: batch = 262144, N = 40, fp32)
+# ------------------------------------------------------------------------------------------------
+def test_full_size_properties_fp32(pkg, orc):
+    rng = np.random.default_rng(0)
+    B = 262144
+    x0 = random_states(rng, B)
+    x0t = T(x0, torch.float32)
+    opt = pkg.BatchOptimization(pkg.default_params(**NO_TOL), max_batch=B, dtype=torch.float32, device=0)
+    out = opt.step(x0t, DYN_UI, 0.0)
+    u, pred, st = out.u.clone(), out.predicted_states.clone(), out.status.clone()
+    ok = st == pkg.capi.TERM["MAX_ITERATIONS"]
+    assert ok.float().mean().item() > 0.999       # a handful of fp32 lanes may report QP_INDEFINITE
+    assert torch.isfinite(u[:, ok]).all() and torch.isfinite(pred[:, :, ok]).all()
+    assert u.abs().max().item() <= 300.0          # retraction clamp (optimization.cc:327)
+    assert (pred[:, 1].abs() <= np.pi + 1e-6).all()  # mod_pi after every predicted step
+    # determinism: same inputs, bitwise the same outputs
+    opt.reset()
+    out2 = opt.step(x0t, DYN_UI, 0.0)
+    assert torch.equal(out2.u, u) and torch.equal(out2.status, st)
+    # batch-position independence: a sub-batch solved alone gives bitwise the same answers
+    idx = torch.arange(1000, 1000 + 4096, device=DEV)
+    small = pkg.BatchOptimization(pkg.default_params(**NO_TOL), max_batch=4096, dtype=torch.float32, device=0)
+    outs = small.step(x0t[:, idx].contiguous(), DYN_UI, 0.0)
+    assert torch.equal(outs.u, u[:, idx])
+    # predicted states are the single-shooting rollout of u (optimization.cc:353-371), re-derived with
+    # the RK4 entry point
+    x = x0t[:, :8192].contiguous()
+    for k in range(40):
+        x = pkg.rk4_batch(DYN_UI, x, u[k, :8192].contiguous(), 0.01, jacobians=False)
+        x[1] = torch.remainder(x[1] + np.pi, 2 * np.pi) - np.pi
+        d = (x - pred[k, :, :8192])
+        d[1] = torch.remainder(d[1] + np.pi, 2 * np.pi) - np.pi
+        assert d.abs().max().item() < 2e-3, k
+    # fp32 against the fp64 oracle on a sample: report, bound loosely (the reference is fp64-only)
+    samp = np.arange(0, B, B // 256)[:256]
+    u_cpu, _, _, _, _ = orc.step_batch_cold(orc.default_opt_params(**NO_TOL), DYN_UI, 0.0, x0[:, samp])
+    err = np.abs(N_(u[:, T(samp, torch.long)]) - u_cpu).max(axis=0)
+    print("fp32 vs fp64 oracle on 256 lanes: |du| median %.2e p90 %.2e max %.2e" % (
+        np.median(err), np.quantile(err, 0.9), err.max()))
+    assert np.median(err) < 5e-2
+
+
+def test_full_size_fp64_sample_parity(pkg, orc):
+    """fp64 at B = 65536: lanes sampled across the batch agree with the oracle to 1e-5."""
+    rng = np.random.default_rng(21)
+    B = 65536
+    x0 = random_states(rng, B)
+    opt = pkg.BatchOptimization(pkg.default_params(**NO_TOL), max_batch=B, dtype=torch.float64, device=0)
+    out = opt.step(T(x0), DYN_UI, 0.0)
+    samp = np.concatenate([np.arange(0, 64), np.arange(B - 64, B), rng.integers(0, B, 384)])
+    u_cpu, _, st_cpu, _, _ = orc.step_batch_cold(orc.default_opt_params(**NO_TOL), DYN_UI, 0.0, x0[:, samp])
+    err = np.abs(N_(out.u)[:, samp] - u_cpu).max(axis=0)
+    assert (N_(out.status)[samp] == st_cpu).all()
+    assert err.max() < 1e-5
+
+
+def test_profiling_counts_launches(pkg):
+    rng = np.random.default_rng(1)
+    B = 256
+    opt = pkg.BatchOptimization(pkg.default_params(max_iterations=5), max_batch=B, dtype=torch.float32, device=0)
+    opt.profile_enable(True)
+    opt.profile_reset()
+    for _ in range(3):
+        opt.step(T(random_states(rng, B), torch.float32), DYN_UI, 0.0)
+    prof = opt.profile_read()
+    assert prof["prepare_kernel"][1] == 3 and prof["finalize_kernel"][1] == 3
+    assert prof["linearize_kernel"][1] == 15 and prof["qp_ls_kernel"][1] == 15
+    assert all(ms > 0 for ms, _ in prof.values())
