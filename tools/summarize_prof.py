@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 output of `tools/prof.sh <tag>` (gpurun_out/prof_<tag>/) into profiles/.
+
+Writes
+  profiles/<tag>_kernel_stats.csv    the --kernel-trace --stats table (our kernels only)
+  profiles/<tag>_pmc_summary.json    per-kernel, per-launch averages of every PMC counter collected
+                                     (separate --pmc passes), plus HBM traffic per launch
+  profiles/traffic_latest.json       {kernel: HBM bytes per launch} read by bench.py ("traffic")
+
+HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE
+come from separate passes, are in KiB, and FETCH_SIZE under-reports by a pattern-dependent factor on
+gfx950 (x2 for 16 B/lane streams; other widths must be calibrated on a known byte count in the same
+access pattern).  Calibration kernel: finalize_kernel, whose traffic is known exactly: it reads
+u (N) + x0 (4) + 5 per-problem scalars and writes u (N) + predicted (4N) + 5 scalars, all as 4- or
+8-byte-per-lane coalesced accesses, the same pattern every other kernel here uses.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    for k in ("qp_ls_kernel", "linearize_kernel", "finalize_kernel", "prepare_kernel", "sim_kernel",
+              "rk4_kernel", "dynamics_kernel"):
+        if k in name:
+            return k
+    return None
+
+
+def read_counters(path):
+    """{kernel: {counter: [values per dispatch]}}; values of one dispatch are summed over rows."""
+    per = defaultdict(lambda: defaultdict(lambda: defaultdict(float)))
+    with open(path) as fh:
+        for row in csv.DictReader(fh):
+            k = short(row["Kernel_Name"])
+            if k is None:
+                continue
+            per[k][row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
+    return {k: {c: list(v.values()) for c, v in cs.items()} for k, cs in per.items()}
+
+
+def main():
+    tag = sys.argv[1]
+    dtype = sys.argv[2] if len(sys.argv) > 2 else "f32"
+    batch = int(sys.argv[3]) if len(sys.argv) > 3 else 262144
+    N = 40
+    src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+    out_dir = os.path.join(ROOT, "profiles")
+    os.makedirs(out_dir, exist_ok=True)
+
+    # kernel stats
+    stats = {}
+    for path in glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv")):
+        with open(path) as fh, open(os.path.join(out_dir, tag + "_kernel_stats.csv"), "w") as out:
+            rd = csv.reader(fh)
+            wr = csv.writer(out)
+            header = next(rd)
+            wr.writerow(header)
+            for row in rd:
+                k = short(row[0])
+                if k:
+                    wr.writerow(row)
+                    stats[k] = {"calls": int(row[1]), "avg_ns": float(row[3]), "pct": float(row[4])}
+    # counters
+    counters = defaultdict(dict)
+    for sub in ("fetch", "write", "sq", "sq2"):
+        for path in glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")):
+            for k, cs in read_counters(path).items():
+                for c, vals in cs.items():
+                    counters[k][c] = sum(vals) / len(vals)
+    esz = 4 if dtype == "f32" else 8
+    known_read = (N + 4) * esz * batch + 5 * 4 * batch      # finalize: u, x0 (R) + status/iters/ls (int) + f, cn
+    known_read = ((N + 4 + 2) * esz + 3 * 4) * batch
+    known_write = ((N + 4 * N + 2) * esz + 3 * 4) * batch
+    summary = {"tag": tag, "dtype": dtype, "batch": batch, "kernel_trace": stats, "pmc_per_launch": counters,
+               "units": "FETCH_SIZE/WRITE_SIZE in KiB as reported by rocprofv3; *_bytes fields are corrected bytes"}
+    traffic = {}
+    fin = counters.get("finalize_kernel", {})
+    cal_r = cal_w = None
+    if "FETCH_SIZE" in fin and fin["FETCH_SIZE"] > 0:
+        cal_r = known_read / (fin["FETCH_SIZE"] * 1024.0)
+    if "WRITE_SIZE" in fin and fin["WRITE_SIZE"] > 0:
+        cal_w = known_write / (fin["WRITE_SIZE"] * 1024.0)
+    summary["calibration"] = {
+        "kernel": "finalize_kernel", "known_read_bytes": known_read, "known_write_bytes": known_write,
+        "fetch_factor": cal_r, "write_factor": cal_w,
+        "note": "factor = known bytes / (counter KiB * 1024); applied to every kernel's counters"}
+    for k, cs in counters.items():
+        if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs and cal_r and cal_w:
+            rb = cs["FETCH_SIZE"] * 1024.0 * cal_r
+            wb = cs["WRITE_SIZE"] * 1024.0 * cal_w
+            traffic[k] = rb + wb
+            t = stats.get(k, {}).get("avg_ns")
+            summary.setdefault("hbm", {})[k] = {
+                "read_bytes": rb, "write_bytes": wb, "bytes_per_problem": (rb + wb) / batch,
+                "GBps": (rb + wb) / t if t else None}
+    for k, cs in counters.items():
+        if "SQ_ACTIVE_INST_VALU" in cs and "SQ_WAVE_CYCLES" in cs and cs["SQ_WAVE_CYCLES"] > 0:
+            summary.setdefault("derived", {})[k] = {
+                "valu_active_over_wave_cycles": cs["SQ_ACTIVE_INST_VALU"] / cs["SQ_WAVE_CYCLES"],
+                "wait_inst_any_over_wave_cycles": cs.get("SQ_WAIT_INST_ANY", 0) / cs["SQ_WAVE_CYCLES"],
+                "wait_any_over_wave_cycles": cs.get("SQ_WAIT_ANY", 0) / cs["SQ_WAVE_CYCLES"],
+                "valu_insts_per_wave": cs.get("SQ_INSTS_VALU", 0) / max(cs.get("SQ_WAVES", 1), 1),
+            }
+    with open(os.path.join(out_dir, tag + "_pmc_summary.json"), "w") as fh:
+        json.dump(summary, fh, indent=1, sort_keys=True)
+    with open(os.path.join(out_dir, "traffic_latest.json"), "w") as fh:
+        json.dump({"tag": tag, "dtype": dtype, "batch": batch, "per_launch_bytes": traffic,
+                   "source": "profiles/%s_pmc_summary.json" % tag}, fh, indent=1, sort_keys=True)
+    print(json.dumps(summary, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main()
