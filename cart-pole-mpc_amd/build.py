@@ -45,5 +45,56 @@ def build_lib(force=False, verbose=False):
     return LIB
 
 
+HOST = os.path.join(HERE, "host")
+HOST_LIB = os.path.join(LIB_DIR, "libpendulum_host.so")
+HOST_SMOKE = os.path.join(LIB_DIR, "host_smoke")
+
+
+def _pymod_path():
+    import sysconfig
+    return os.path.join(LIB_DIR, "pypendulum" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_host(force=False, verbose=False):
+    """C++ facade (pendulum::Optimization / Simulator over the C-ABI), the pypendulum module
+    (pybind11) and the C++ closed-loop smoke binary.  Plain g++: the facade only sees include/cpmpc.h."""
+    import sysconfig
+
+    build_lib()
+    srcs = [os.path.join(HOST, f) for f in ("optimization.cc", "simulator.cc")]
+    hdrs = [os.path.join(HOST, f) for f in ("optimization.hpp", "simulator.hpp", "structs.hpp")]
+    cxx = os.environ.get("CXX", "g++")
+    common = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-Wextra"]
+    link = ["-L" + LIB_DIR, "-lcpmpc", "-Wl,-rpath,$ORIGIN"]
+
+    def stale(target, deps):
+        return force or not os.path.exists(target) or any(os.path.getmtime(d) > os.path.getmtime(target)
+                                                          for d in deps + [LIB])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+
+    if stale(HOST_LIB, srcs + hdrs):
+        run([cxx] + common + ["-shared", "-o", HOST_LIB] + srcs + link)
+    smoke_src = os.path.join(HOST, "host_smoke.cc")
+    if stale(HOST_SMOKE, [smoke_src, HOST_LIB] + hdrs):
+        run([cxx] + common + ["-o", HOST_SMOKE, smoke_src, "-L" + LIB_DIR, "-lpendulum_host", "-lcpmpc",
+                              "-Wl,-rpath,$ORIGIN"])
+    try:
+        import pybind11
+    except ImportError:
+        return HOST_LIB  # facade built; Python binding needs pybind11
+    mod = _pymod_path()
+    mod_src = os.path.join(HOST, "pypendulum.cc")
+    if stale(mod, [mod_src, HOST_LIB] + hdrs):
+        run([cxx] + common + ["-shared", "-fvisibility=hidden", "-o", mod, mod_src,
+                              "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"],
+                              "-L" + LIB_DIR, "-lpendulum_host", "-lcpmpc", "-Wl,-rpath,$ORIGIN"])
+    return mod
+
+
 if __name__ == "__main__":
     print(build_lib(force="--force" in sys.argv, verbose=True))
+    print(build_host(force="--force" in sys.argv, verbose=True))

@@ -29,7 +29,7 @@ SYMBOLS = [
     "cpmpc_has_previous_solution", "cpmpc_dim", "cpmpc_num_states", "cpmpc_dtype",
     "cpmpc_step_batch_host", "cpmpc_set_previous_solution_host", "cpmpc_get_solution_host",
     "cpmpc_dynamics_batch", "cpmpc_rk4_batch", "cpmpc_linearize_batch", "cpmpc_sim_step_batch",
-    "cpmpc_profile_enable", "cpmpc_profile_reset", "cpmpc_profile_read", "cpmpc_kernel_name",
+    "cpmpc_sim_step_batch_host", "cpmpc_profile_enable", "cpmpc_profile_reset", "cpmpc_profile_read", "cpmpc_kernel_name",
 ]
 
 
@@ -142,6 +142,7 @@ def load():
     L.cpmpc_rk4_batch.argtypes = [i32, i64, _dp, vp, vp, dbl, _dp, vp, vp, vp, vp]
     L.cpmpc_linearize_batch.argtypes = [vp, i64, _dp, vp, vp, vp, vp, vp]
     L.cpmpc_sim_step_batch.argtypes = [i32, i64, _dp, dbl, vp, _dp, vp, vp, vp]
+    L.cpmpc_sim_step_batch_host.argtypes = [i64, _dp, dbl, _dp, _dp, _dp]
     L.cpmpc_profile_enable.argtypes = [vp, i32]
     L.cpmpc_profile_reset.argtypes = [vp]
     L.cpmpc_profile_read.argtypes = [vp, i32, _dp, C.POINTER(C.c_int64)]

@@ -773,3 +773,30 @@ extern "C" int cpmpc_sim_step_batch(int dtype, int64_t B, const double* dyn_shar
   HIP_TRY(hipGetLastError());
   return CPMPC_OK;
 }
+
+extern "C" int cpmpc_sim_step_batch_host(int64_t B, const double* dyn_shared_host, double dt, const double* u_host,
+                                         const double* fext_host, double* state_host) {
+  if (!dyn_shared_host || !u_host || !state_host) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
+  if (B < 1) return fail(CPMPC_ERR_INVALID_ARG, "B must be >= 1");
+  for (int64_t i = 0; i < B; ++i)
+    if (!std::isfinite(u_host[i])) return fail(CPMPC_ERR_INVALID_ARG, "u = %g is not finite (simulator.cc:14)", u_host[i]);
+  int rc = current_device_ok();
+  if (rc) return rc;
+  double* d = nullptr;
+  HIP_TRY(hipMalloc((void**)&d, (size_t)5 * (size_t)B * sizeof(double)));
+  double* d_state = d;
+  double* d_u = d + 4 * B;
+  hipError_t e = hipMemcpy(d_state, state_host, (size_t)4 * B * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_u, u_host, (size_t)B * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    rc = cpmpc_sim_step_batch(CPMPC_F64, B, dyn_shared_host, dt, d_u, fext_host, nullptr, d_state, nullptr);
+    if (rc == CPMPC_OK) {
+      e = hipStreamSynchronize(nullptr);
+      if (e == hipSuccess) e = hipMemcpy(state_host, d_state, (size_t)4 * B * sizeof(double), hipMemcpyDeviceToHost);
+    }
+  }
+  (void)hipFree(d);
+  if (rc) return rc;
+  if (e != hipSuccess) return fail(CPMPC_ERR_HIP, "HIP copy failed: %s", hipGetErrorString(e));
+  return CPMPC_OK;
+}

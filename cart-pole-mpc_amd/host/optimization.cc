@@ -1,0 +1,141 @@
+// optimization.cc -- pendulum::Optimization over the C-ABI (include/cpmpc.h).
+// Mirrors the call sequence of the reference's Optimization::Step (optimization/optimization.cc:39-97);
+// the numerical work happens in libcpmpc.so's HIP kernels.
+#include "optimization.hpp"
+
+#include <sstream>
+#include <stdexcept>
+
+#include "../../include/cpmpc.h"
+
+namespace pendulum {
+
+static const char* TerminationName(NLSTerminationState s) {
+  switch (s) {
+    case NLSTerminationState::NONE: return "NONE";
+    case NLSTerminationState::MAX_ITERATIONS: return "MAX_ITERATIONS";
+    case NLSTerminationState::SATISFIED_ABSOLUTE_TOL: return "SATISFIED_ABSOLUTE_TOL";
+    case NLSTerminationState::SATISFIED_RELATIVE_TOL: return "SATISFIED_RELATIVE_TOL";
+    case NLSTerminationState::SATISFIED_FIRST_ORDER_TOL: return "SATISFIED_FIRST_ORDER_TOL";
+    case NLSTerminationState::QP_INDEFINITE: return "QP_INDEFINITE";
+    case NLSTerminationState::USER_CALLBACK: return "USER_CALLBACK";
+    case NLSTerminationState::MAX_LAMBDA: return "MAX_LAMBDA";
+    case NLSTerminationState::NON_FINITE: return "NON_FINITE";
+  }
+  return "?";
+}
+
+std::string NLSSolverOutputs::ToString() const {
+  std::ostringstream os;
+  os << "Iterations: " << iterations << ", termination = " << TerminationName(termination_state)
+     << "\n  final cost (1/2 |r|^2) = " << final_cost << ", final |c|_1 = " << final_equality_l1 << "\n";
+  return os.str();
+}
+
+static cpmpc_params ToC(const OptimizationParams& p) {
+  cpmpc_params c;
+  c.control_dt = p.control_dt;
+  c.window_length = p.window_length;
+  c.state_spacing = p.state_spacing;
+  c.max_iterations = p.max_iterations;
+  c.relative_exit_tol = p.relative_exit_tol;
+  c.absolute_first_derivative_tol = p.absolute_first_derivative_tol;
+  c.equality_penalty_initial = p.equality_penalty_initial;
+  c.u_guess_sinusoid_amplitude = p.u_guess_sinusoid_amplitude;
+  c.u_cost_weight = p.u_cost_weight;
+  c.u_derivative_cost_weight = p.u_derivative_cost_weight;
+  c.b_x_final_cost_weight = p.b_x_final_cost_weight;
+  c.th_final_cost_weight = p.th_final_cost_weight;
+  c.b_x_dot_final_cost_weight = p.b_x_dot_final_cost_weight;
+  c.th_dot_final_cost_weight = p.th_dot_final_cost_weight;
+  return c;
+}
+
+[[noreturn]] static void Throw(int rc) {
+  const std::string text = std::string("cpmpc: ") + cpmpc_last_error();
+  if (rc == CPMPC_ERR_INVALID_ARG) throw std::invalid_argument(text);
+  throw std::runtime_error(text);
+}
+
+Optimization::Optimization(const OptimizationParams& params, std::size_t max_batch, int device)
+    : params_(params), max_batch_(max_batch) {
+  const cpmpc_params c = ToC(params);
+  // fp64, like the reference.
+  const int rc = cpmpc_create(&c, nullptr, CPMPC_F64, static_cast<std::int64_t>(max_batch), device, &solver_);
+  if (rc != CPMPC_OK) Throw(rc);
+}
+
+Optimization::~Optimization() { cpmpc_destroy(solver_); }
+
+void Optimization::Reset() {
+  previous_solution_.resize(0);
+  cpmpc_reset(solver_);
+}
+
+void Optimization::SetPreviousSolution(const std::vector<double>& guess) {
+  if (static_cast<int>(guess.size()) != cpmpc_dim(solver_)) {
+    // the reference would fail later inside the solver on a wrongly sized guess; fail here instead
+    throw std::invalid_argument("SetPreviousSolution: guess has the wrong dimension");
+  }
+  previous_solution_ = guess;
+  const int rc = cpmpc_set_previous_solution_host(solver_, 1, guess.data());
+  if (rc != CPMPC_OK) Throw(rc);
+}
+
+OptimizationOutputs Optimization::Step(const SingleCartPoleState& current_state,
+                                       const SingleCartPoleParams& dynamics_params,
+                                       const double b_x_set_point) {
+  const std::size_t N = params_.window_length;
+  const auto x0 = current_state.ToVector();
+  const auto dyn = dynamics_params.ToArray();
+  std::vector<double> u(N), pred(4 * N);
+  std::int32_t status = 0, iterations = 0;
+  double cost = 0.0, eq = 0.0;
+  int rc = cpmpc_step_batch_host(solver_, 1, x0.data(), dyn.data(), b_x_set_point, u.data(), pred.data(),
+                                 &status, &iterations, &cost, &eq);
+  if (rc != CPMPC_OK) Throw(rc);
+
+  OptimizationOutputs out;
+  out.initial_state = current_state;
+  out.previous_solution = previous_solution_;  // the solution the guess was shifted from (optimization.cc:84)
+  out.solver_outputs.termination_state = static_cast<NLSTerminationState>(status);
+  out.solver_outputs.iterations = iterations;
+  out.solver_outputs.final_cost = cost;
+  out.solver_outputs.final_equality_l1 = eq;
+  out.u = std::move(u);
+  out.predicted_states.reserve(N);
+  for (std::size_t k = 0; k < N; ++k)  // [N][4][1]
+    out.predicted_states.emplace_back(pred[4 * k + 0], pred[4 * k + 1], pred[4 * k + 2], pred[4 * k + 3]);
+
+  previous_solution_.resize(static_cast<std::size_t>(cpmpc_dim(solver_)));
+  rc = cpmpc_get_solution_host(solver_, 1, previous_solution_.data());  // optimization.cc:85
+  if (rc != CPMPC_OK) Throw(rc);
+  return out;
+}
+
+BatchOptimizationOutputs Optimization::StepBatch(const std::vector<double>& states_soa,
+                                                 const SingleCartPoleParams& dynamics_params,
+                                                 const double b_x_set_point) {
+  if (states_soa.empty() || states_soa.size() % 4 != 0)
+    throw std::invalid_argument("StepBatch: states_soa must be [4][B]");
+  const std::size_t B = states_soa.size() / 4;
+  if (B > max_batch_) throw std::invalid_argument("StepBatch: batch exceeds the capacity given at construction");
+  const std::size_t N = params_.window_length;
+  const auto dyn = dynamics_params.ToArray();
+  BatchOptimizationOutputs out;
+  out.batch = B;
+  out.u.resize(N * B);
+  out.predicted_states.resize(4 * N * B);
+  out.status.resize(B);
+  out.iterations.resize(B);
+  out.final_cost.resize(B);
+  out.final_equality_l1.resize(B);
+  const int rc = cpmpc_step_batch_host(solver_, static_cast<std::int64_t>(B), states_soa.data(), dyn.data(),
+                                       b_x_set_point, out.u.data(), out.predicted_states.data(),
+                                       out.status.data(), out.iterations.data(), out.final_cost.data(),
+                                       out.final_equality_l1.data());
+  if (rc != CPMPC_OK) Throw(rc);
+  return out;
+}
+
+}  // namespace pendulum

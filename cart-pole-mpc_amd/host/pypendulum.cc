@@ -1,0 +1,91 @@
+// pypendulum.cc -- Python module `pypendulum` with the names of the reference's nanobind wrapper
+// (wrapper/wrapper.cc:40-98), bound with pybind11 over the C++ facade (nanobind is not available
+// in this image).  Additions, all batched: Optimization(params, max_batch), .step_batch(),
+// .reset(); Simulator.set_state().
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include "optimization.hpp"
+#include "simulator.hpp"
+
+namespace py = pybind11;
+using namespace pendulum;
+
+PYBIND11_MODULE(pypendulum, m) {
+  m.doc() = "cart-pole MPC (MI355X-native hot path); API of gareth-cross/cart-pole-mpc's pypendulum";
+
+  py::class_<SingleCartPoleParams>(m, "SingleCartPoleParams")
+      .def(py::init<>())
+      .def(py::init<double, double, double, double, double, double, double, double, double>(), py::arg("m_b"),
+           py::arg("m_1"), py::arg("l_1"), py::arg("g"), py::arg("mu_b"), py::arg("v_mu_b"), py::arg("c_d_1"),
+           py::arg("x_s"), py::arg("k_s"))
+      .def_readwrite("m_b", &SingleCartPoleParams::m_b)
+      .def_readwrite("m_1", &SingleCartPoleParams::m_1)
+      .def_readwrite("l_1", &SingleCartPoleParams::l_1)
+      .def_readwrite("g", &SingleCartPoleParams::g)
+      .def_readwrite("mu_b", &SingleCartPoleParams::mu_b)
+      .def_readwrite("v_mu_b", &SingleCartPoleParams::v_mu_b)
+      .def_readwrite("c_d_1", &SingleCartPoleParams::c_d_1)
+      .def_readwrite("x_s", &SingleCartPoleParams::x_s)
+      .def_readwrite("k_s", &SingleCartPoleParams::k_s);
+
+  py::class_<OptimizationParams>(m, "OptimizationParams")
+      .def(py::init<>())
+      .def_readwrite("control_dt", &OptimizationParams::control_dt)
+      .def_readwrite("window_length", &OptimizationParams::window_length)
+      .def_readwrite("state_spacing", &OptimizationParams::state_spacing)
+      .def_readwrite("max_iterations", &OptimizationParams::max_iterations)
+      .def_readwrite("relative_exit_tol", &OptimizationParams::relative_exit_tol)
+      .def_readwrite("absolute_first_derivative_tol", &OptimizationParams::absolute_first_derivative_tol)
+      .def_readwrite("equality_penalty_initial", &OptimizationParams::equality_penalty_initial)
+      .def_readwrite("u_guess_sinusoid_amplitude", &OptimizationParams::u_guess_sinusoid_amplitude)
+      .def_readwrite("u_cost_weight", &OptimizationParams::u_cost_weight)
+      .def_readwrite("u_derivative_cost_weight", &OptimizationParams::u_derivative_cost_weight)
+      .def_readwrite("b_x_final_cost_weight", &OptimizationParams::b_x_final_cost_weight)
+      .def_readwrite("th_final_cost_weight", &OptimizationParams::th_final_cost_weight)
+      .def_readwrite("b_x_dot_final_cost_weight", &OptimizationParams::b_x_dot_final_cost_weight)
+      .def_readwrite("th_dot_final_cost_weight", &OptimizationParams::th_dot_final_cost_weight);
+
+  py::class_<SingleCartPoleState>(m, "SingleCartPoleState")
+      .def(py::init<double, double, double, double>())
+      .def_readwrite("b_x", &SingleCartPoleState::b_x)
+      .def_readwrite("th_1", &SingleCartPoleState::th_1)
+      .def_readwrite("b_x_dot", &SingleCartPoleState::b_x_dot)
+      .def_readwrite("th_1_dot", &SingleCartPoleState::th_1_dot);
+
+  py::class_<OptimizationOutputs>(m, "OptimizationOutputs")
+      .def("solver_summary", [](const OptimizationOutputs& self) { return self.solver_outputs.ToString(); })
+      .def_property_readonly("termination_state",
+                             [](const OptimizationOutputs& self) {
+                               return static_cast<int>(self.solver_outputs.termination_state);
+                             })
+      .def_readonly("previous_solution", &OptimizationOutputs::previous_solution)
+      .def_readonly("u", &OptimizationOutputs::u)
+      .def_readonly("predicted_states", &OptimizationOutputs::predicted_states);
+
+  py::class_<BatchOptimizationOutputs>(m, "BatchOptimizationOutputs")
+      .def_readonly("batch", &BatchOptimizationOutputs::batch)
+      .def_readonly("u", &BatchOptimizationOutputs::u)
+      .def_readonly("predicted_states", &BatchOptimizationOutputs::predicted_states)
+      .def_readonly("status", &BatchOptimizationOutputs::status)
+      .def_readonly("iterations", &BatchOptimizationOutputs::iterations)
+      .def_readonly("final_cost", &BatchOptimizationOutputs::final_cost)
+      .def_readonly("final_equality_l1", &BatchOptimizationOutputs::final_equality_l1);
+
+  py::class_<Optimization>(m, "Optimization")
+      .def(py::init<const OptimizationParams&>())
+      .def(py::init<const OptimizationParams&, std::size_t, int>(), py::arg("params"), py::arg("max_batch"),
+           py::arg("device") = 0)
+      .def("step", &Optimization::Step)
+      .def("step_batch", &Optimization::StepBatch)
+      .def("reset", &Optimization::Reset)
+      .def("set_previous_solution", &Optimization::SetPreviousSolution);
+
+  py::class_<Vector2>(m, "Vector2").def(py::init<double, double>());
+
+  py::class_<Simulator>(m, "Simulator")
+      .def(py::init<>())
+      .def("step", &Simulator::Step)
+      .def("get_state", &Simulator::GetState)
+      .def("set_state", &Simulator::SetState);
+}

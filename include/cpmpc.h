@@ -197,6 +197,11 @@ int cpmpc_sim_step_batch(int dtype, int64_t B, const double* dyn_shared_host, do
                          const void* u, const double* fext_host, const void* fext, void* state,
                          void* stream);
 
+/* Host-pointer convenience for Simulator::Step (fp64 on the GPU; used by the C++ facade):
+ * state_host [4][B] in/out, u_host [B], fext_host shared or NULL.  No CPU compute path. */
+int cpmpc_sim_step_batch_host(int64_t B, const double* dyn_shared_host, double dt,
+                              const double* u_host, const double* fext_host, double* state_host);
+
 /* ---- measurement ------------------------------------------------------------------------------ */
 
 enum {
