@@ -59,6 +59,7 @@ class SolverOpts(C.Structure):
         ("armijo_c1", C.c_double),
         ("ls_shrink_max", C.c_double),
         ("ls_shrink_min", C.c_double),
+        ("ls_alpha_growth", C.c_double),
         ("penalty_rho", C.c_double),
         ("lambda_initial", C.c_double),
         ("lambda_failure_init", C.c_double),

@@ -18,32 +18,80 @@ namespace cpmpc {
 template <typename R>
 struct Math;
 
+#ifndef CPMPC_F32_LIBM
+#define CPMPC_F32_LIBM 0  // 1: ocml sincosf/tanhf/sqrtf and IEEE division in the fp32 kernels
+#endif
+
+// fp32: the reference is fp64-only, so the fp32 kernels are free to use bounded-range routines.
+// Angles reaching sincos are at most a few turns (theta is wrapped to (-pi, pi] at every shooting node
+// and RK4 stages move it by < 1 rad), where a 3-term Cody-Waite reduction by pi/2 and degree-7/8
+// minimax polynomials are accurate to ~1 ulp; tanh uses the hardware exp2; sqrt and reciprocal use the
+// 1-ulp hardware instructions.
 template <>
 struct Math<float> {
+#if CPMPC_F32_LIBM
   static __device__ __forceinline__ void sincos(float x, float& s, float& c) { ::sincosf(x, &s, &c); }
   static __device__ __forceinline__ float tanh(float x) { return ::tanhf(x); }
   static __device__ __forceinline__ float sqrt(float x) { return ::sqrtf(x); }
+  static __device__ __forceinline__ float rcp(float x) { return 1.0f / x; }
+#else
+  static __device__ __forceinline__ void sincos(float x, float& s, float& c) {
+    const float kf = ::rintf(x * 0.63661977236758134f);  // nearest multiple of pi/2
+    float r = ::fmaf(-kf, 1.5703125f, x);                // pi/2 split in three (Cody-Waite)
+    r = ::fmaf(-kf, 4.837512969970703125e-4f, r);
+    r = ::fmaf(-kf, 7.54978995489188e-8f, r);
+    const int q = (int)kf;
+    const float r2 = r * r;
+    float sp = ::fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+    sp = ::fmaf(sp, r2, -1.6666654611e-1f);
+    sp = ::fmaf(sp * r2, r, r);
+    float cp = ::fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    cp = ::fmaf(cp, r2, 4.166664568298827e-2f);
+    cp = ::fmaf(cp * r2, r2, ::fmaf(r2, -0.5f, 1.0f));
+    const bool swap = q & 1;
+    const float ss = swap ? cp : sp;
+    const float cc = swap ? sp : cp;
+    s = (q & 2) ? -ss : ss;
+    c = ((q + 1) & 2) ? -cc : cc;
+  }
+  static __device__ __forceinline__ float tanh(float x) {
+    const float t = __expf(-2.0f * ::fabsf(x));  // in (0, 1]
+    const float r = (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);
+    return ::copysignf(r, x);
+  }
+  static __device__ __forceinline__ float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+  static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+#endif
   static __device__ __forceinline__ float fabs(float x) { return ::fabsf(x); }
-  static __device__ __forceinline__ float fmod(float x, float y) { return ::fmodf(x, y); }
+  static __device__ __forceinline__ float trunc(float x) { return ::truncf(x); }
+  static __device__ __forceinline__ float fma(float a, float b, float c) { return ::fmaf(a, b, c); }
   static __device__ __forceinline__ bool finite(float x) { return ::isfinite(x); }
 };
 
+// fp64: the parity dtype; correctly rounded library routines.
 template <>
 struct Math<double> {
   static __device__ __forceinline__ void sincos(double x, double& s, double& c) { ::sincos(x, &s, &c); }
   static __device__ __forceinline__ double tanh(double x) { return ::tanh(x); }
   static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
+  static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
   static __device__ __forceinline__ double fabs(double x) { return ::fabs(x); }
-  static __device__ __forceinline__ double fmod(double x, double y) { return ::fmod(x, y); }
+  static __device__ __forceinline__ double trunc(double x) { return ::trunc(x); }
+  static __device__ __forceinline__ double fma(double a, double b, double c) { return ::fma(a, b, c); }
   static __device__ __forceinline__ bool finite(double x) { return ::isfinite(x); }
 };
 
 // Map an angle to (-pi, pi]; same cut as integration.hpp:65-73 (mod_pi(+-pi) = +pi).
+// fmod(a, 2pi) is evaluated as a - trunc(a/2pi)*2pi with one fused multiply-add: the exact remainder
+// is representable, so the fma returns it exactly whenever the quotient is right, and a quotient off
+// by one (a within an ulp of a multiple of 2pi) is repaired by the two range fix-ups below.
 template <typename R>
 __device__ __forceinline__ R mod_pi(R angle) {
   constexpr R pi = static_cast<R>(3.14159265358979323846);
   constexpr R two_pi = 2 * pi;
-  angle = Math<R>::fmod(angle, two_pi);
+  constexpr R inv_two_pi = static_cast<R>(0.15915494309189533577);
+  const R n = Math<R>::trunc(angle * inv_two_pi);
+  angle = Math<R>::fma(-n, two_pi, angle);
   angle += (angle < R(0)) ? two_pi : R(0);
   angle -= (angle > pi) ? two_pi : R(0);
   return angle;
@@ -141,7 +189,7 @@ __device__ __forceinline__ void cartpole_accel(const CartPoleConsts<R>& k, const
   }
 
   const R den = k.mt - k.m_1 * s * s;
-  const R inv_den = R(1) / den;
+  const R inv_den = Math<R>::rcp(den);
   const R sl = s * k.inv_L;
   const R N_x = F_b + sl * F_th;
   const R N_th = sl * F_b + k.kap * F_th;
@@ -152,7 +200,7 @@ __device__ __forceinline__ void cartpole_accel(const CartPoleConsts<R>& k, const
     // partials of the drag terms with respect to (th, v, w)
     R dDx0 = R(0), dDx1 = R(0), dDx2 = R(0), dDt0 = R(0), dDt1 = R(0), dDt2 = R(0);
     if (on_d) {
-      const R inv_n = R(1) / n;
+      const R inv_n = Math<R>::rcp(n);
       // d|v|/d(th, v, w)
       const R dn0 = (vx * (-Lw * c) + vy * (-Lw * s)) * inv_n;
       const R dn1 = vx * inv_n;

@@ -66,6 +66,7 @@ extern "C" void cpmpc_default_solver_opts(cpmpc_solver_opts* o) {
   o->armijo_c1 = 1.0e-4;
   o->ls_shrink_max = 0.5;
   o->ls_shrink_min = 0.1;
+  o->ls_alpha_growth = 2.0;
   o->penalty_rho = 0.1;
   o->lambda_initial = 0.0;
   o->lambda_failure_init = 1.0e-2;
@@ -138,7 +139,7 @@ struct cpmpc_solver {
   // one allocation, carved into fields
   void* ws = nullptr;
   size_t ws_bytes = 0;
-  char *z, *dz, *Phi, *Gam, *cs, *vv, *uu, *dd, *sc;
+  char *zx, *zu, *dzx, *dzu, *Phi, *Gam, *cs, *Wk, *Tk, *sc;
   int32_t* ist;
   void* sin_table = nullptr;
   int has_prev = 0;
@@ -206,7 +207,8 @@ extern "C" int cpmpc_create(const cpmpc_params* params, const cpmpc_solver_opts*
   s->dim = 4 * s->S + s->N;
   s->cap = (max_batch + 63) / 64 * 64;
 
-  const size_t fields_real = (size_t)2 * s->dim + 16 * (s->S - 1) + 4 * s->N + 4 * (s->S - 1) + 3 * s->N + SC_COUNT;
+  // scalars of the dtype per problem: 4-vector fields count 4 (nodes, dz nodes, Phi rows, Gamma, defects, W, T)
+  const size_t fields_real = (size_t)4 * (2 * s->S + 4 * (s->S - 1) + s->N + (s->S - 1) + 2 * s->N) + 2 * s->N + SC_COUNT;
   const size_t bytes_real = fields_real * (size_t)s->cap * s->esize;
   const size_t bytes_int = (size_t)IS_COUNT * (size_t)s->cap * sizeof(int32_t);
   s->ws_bytes = bytes_real + bytes_int;
@@ -223,14 +225,16 @@ extern "C" int cpmpc_create(const cpmpc_params* params, const cpmpc_solver_opts*
     pch += nfields * (size_t)s->cap * s->esize;
     return r;
   };
-  s->z = carve(s->dim);
-  s->dz = carve(s->dim);
+  // 4-vector fields first so that every one of them is 16/32-byte aligned (cap is a multiple of 64)
+  s->zx = carve(4 * s->S);
+  s->dzx = carve(4 * s->S);
   s->Phi = carve(16 * (s->S - 1));
   s->Gam = carve(4 * s->N);
   s->cs = carve(4 * (s->S - 1));
-  s->vv = carve(s->N);
-  s->uu = carve(s->N);
-  s->dd = carve(s->N);
+  s->Wk = carve(4 * s->N);
+  s->Tk = carve(4 * s->N);
+  s->zu = carve(s->N);
+  s->dzu = carve(s->N);
   s->sc = carve(SC_COUNT);
   s->ist = (int32_t*)pch;
 
@@ -385,6 +389,7 @@ static void fill_args(const cpmpc_solver* s, int64_t B, SolverArgs<R>& a) {
   a.c1 = (R)o.armijo_c1;
   a.shrink_max = (R)o.ls_shrink_max;
   a.shrink_min = (R)o.ls_shrink_min;
+  a.alpha_growth = (R)o.ls_alpha_growth;
   a.rho = (R)o.penalty_rho;
   a.lam_init = (R)o.lambda_initial;
   a.lam_fail_init = (R)o.lambda_failure_init;
@@ -397,29 +402,29 @@ static void fill_args(const cpmpc_solver* s, int64_t B, SolverArgs<R>& a) {
   a.rel_tol = (R)p.relative_exit_tol;
   a.fo_tol = (R)p.absolute_first_derivative_tol;
   a.mu_init = (R)p.equality_penalty_initial;
-  a.sin_amp = (R)p.u_guess_sinusoid_amplitude;
   a.has_prev = s->has_prev;
-  a.z = (R*)s->z;
-  a.dz = (R*)s->dz;
-  a.Phi = (R*)s->Phi;
-  a.Gam = (R*)s->Gam;
-  a.cs = (R*)s->cs;
-  a.vv = (R*)s->vv;
-  a.uu = (R*)s->uu;
-  a.dd = (R*)s->dd;
+  using V4 = typename VecT<R>::V4;
+  a.zx = (V4*)s->zx;
+  a.zu = (R*)s->zu;
+  a.dzx = (V4*)s->dzx;
+  a.dzu = (R*)s->dzu;
+  a.Phi = (V4*)s->Phi;
+  a.Gam = (V4*)s->Gam;
+  a.cs = (V4*)s->cs;
+  a.Wk = (V4*)s->Wk;
+  a.Tk = (V4*)s->Tk;
   a.sc = (R*)s->sc;
   a.ist = s->ist;
   a.sin_table = (const R*)s->sin_table;
 }
 
 template <typename R>
-static void launch_linearize(const SolverArgs<R>& a, int SP, const R* z_in, R* c_out, R* Phi_out, R* Gam_out,
+static void launch_linearize(const SolverArgs<R>& a, int SP, const typename VecT<R>::V4* zx_in, const R* zu_in,
                              const int32_t* status, hipStream_t stream) {
   const dim3 grid = grid_for(a.B * (a.S - 1));
-#define CPMPC_LIN(SPV)                                                                                     \
-  case SPV:                                                                                                \
-    hipLaunchKernelGGL((linearize_kernel<R, SPV>), grid, dim3(64), 0, stream, a, z_in, c_out, Phi_out,     \
-                       Gam_out, status);                                                                   \
+#define CPMPC_LIN(SPV)                                                                                       \
+  case SPV:                                                                                                  \
+    hipLaunchKernelGGL((linearize_kernel<R, SPV>), grid, dim3(64), 0, stream, a, zx_in, zu_in, status);      \
     break;
   switch (SP) {
     CPMPC_LIN(1)
@@ -466,10 +471,10 @@ static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* 
 
   for (int it = 0; it < (int)s->params.max_iterations; ++it) {
     span_begin(s, CPMPC_KERNEL_LINEARIZE, stream, &sp);
-    launch_linearize<R>(a, s->SP, a.z, a.cs, a.Phi, a.Gam, a.ist, stream);
+    launch_linearize<R>(a, s->SP, a.zx, a.zu, a.ist, stream);
     span_end(s, stream, &sp);
     span_begin(s, CPMPC_KERNEL_QP_LS, stream, &sp);
-    hipLaunchKernelGGL((qp_ls_kernel<R>), gridB, dim3(64), 0, stream, a, it);
+    hipLaunchKernelGGL((qp_ls_kernel<R>), gridB, dim3(64), 0, stream, a);
     span_end(s, stream, &sp);
   }
 
@@ -504,9 +509,14 @@ extern "C" int cpmpc_set_previous_solution(cpmpc_solver* s, int64_t B, const voi
   if (!s || !z) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
   if (B < 1 || B > s->cap) return fail(CPMPC_ERR_BATCH, "B out of range");
   DeviceGuard guard(s->device);
-  // [dim][B] packed -> [dim][cap] strided
-  HIP_TRY(hipMemcpy2DAsync(s->z, (size_t)s->cap * s->esize, z, (size_t)B * s->esize, (size_t)B * s->esize,
-                           (size_t)s->dim, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  // packed [dim][B] (MapKey order) -> workspace layout
+  if (s->dtype == CPMPC_F32)
+    hipLaunchKernelGGL((pack_z_kernel<float>), grid_for(B), dim3(64), 0, (hipStream_t)stream, B, s->cap, s->S, s->N,
+                       (const float*)z, (float4*)s->zx, (float*)s->zu);
+  else
+    hipLaunchKernelGGL((pack_z_kernel<double>), grid_for(B), dim3(64), 0, (hipStream_t)stream, B, s->cap, s->S, s->N,
+                       (const double*)z, (double4*)s->zx, (double*)s->zu);
+  HIP_TRY(hipGetLastError());
   s->has_prev = 1;
   return CPMPC_OK;
 }
@@ -515,8 +525,13 @@ extern "C" int cpmpc_get_solution(cpmpc_solver* s, int64_t B, void* z_out, void*
   if (!s || !z_out) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
   if (B < 1 || B > s->cap) return fail(CPMPC_ERR_BATCH, "B out of range");
   DeviceGuard guard(s->device);
-  HIP_TRY(hipMemcpy2DAsync(z_out, (size_t)B * s->esize, s->z, (size_t)s->cap * s->esize, (size_t)B * s->esize,
-                           (size_t)s->dim, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  if (s->dtype == CPMPC_F32)
+    hipLaunchKernelGGL((unpack_z_kernel<float>), grid_for(B), dim3(64), 0, (hipStream_t)stream, B, s->cap, s->S,
+                       s->N, (const float4*)s->zx, (const float*)s->zu, (float*)z_out);
+  else
+    hipLaunchKernelGGL((unpack_z_kernel<double>), grid_for(B), dim3(64), 0, (hipStream_t)stream, B, s->cap, s->S,
+                       s->N, (const double4*)s->zx, (const double*)s->zu, (double*)z_out);
+  HIP_TRY(hipGetLastError());
   return CPMPC_OK;
 }
 
@@ -719,20 +734,28 @@ extern "C" int cpmpc_linearize_batch(cpmpc_solver* s, int64_t B, const double* d
   if (!s || !dyn_shared_host || !z || !c || !Phi || !Gamma) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
   if (B < 1) return fail(CPMPC_ERR_INVALID_ARG, "B must be >= 1");
   DeviceGuard guard(s->device);
+  if (B > s->cap) return fail(CPMPC_ERR_BATCH, "B exceeds capacity");
+  // the caller's z is packed into the step buffers (dzx/dzu), which hold no state between calls, so the
+  // warm start (zx/zu) is untouched; the linearisation lands in the workspace and is unpacked
+  hipStream_t st = (hipStream_t)stream;
   if (s->dtype == CPMPC_F32) {
     SolverArgs<float> a;
     fill_args<float>(s, B, a);
-    a.stride = B;  // caller arrays are packed [field][B]
     a.consts = make_consts<float, double>(dyn_shared_host);
-    launch_linearize<float>(a, s->SP, (const float*)z, (float*)c, (float*)Phi, (float*)Gamma, nullptr,
-                            (hipStream_t)stream);
+    hipLaunchKernelGGL((pack_z_kernel<float>), grid_for(B), dim3(64), 0, st, B, s->cap, s->S, s->N, (const float*)z,
+                       a.dzx, a.dzu);
+    launch_linearize<float>(a, s->SP, a.dzx, a.dzu, nullptr, st);
+    hipLaunchKernelGGL((unpack_lin_kernel<float>), grid_for(B), dim3(64), 0, st, a, (float*)c, (float*)Phi,
+                       (float*)Gamma);
   } else {
     SolverArgs<double> a;
     fill_args<double>(s, B, a);
-    a.stride = B;
     a.consts = make_consts<double, double>(dyn_shared_host);
-    launch_linearize<double>(a, s->SP, (const double*)z, (double*)c, (double*)Phi, (double*)Gamma, nullptr,
-                             (hipStream_t)stream);
+    hipLaunchKernelGGL((pack_z_kernel<double>), grid_for(B), dim3(64), 0, st, B, s->cap, s->S, s->N, (const double*)z,
+                       a.dzx, a.dzu);
+    launch_linearize<double>(a, s->SP, a.dzx, a.dzu, nullptr, st);
+    hipLaunchKernelGGL((unpack_lin_kernel<double>), grid_for(B), dim3(64), 0, st, a, (double*)c, (double*)Phi,
+                       (double*)Gamma);
   }
   HIP_TRY(hipGetLastError());
   return CPMPC_OK;

@@ -84,6 +84,7 @@ typedef struct cpmpc_solver_opts {
   double armijo_c1;
   double ls_shrink_max;
   double ls_shrink_min;
+  double ls_alpha_growth;
   double penalty_rho;
   double lambda_initial;
   double lambda_failure_init;

@@ -50,6 +50,7 @@ void orc_default_solver_opts(orc_solver_opts* o) {
   o->armijo_c1 = 1.0e-4;
   o->ls_shrink_max = 0.5;
   o->ls_shrink_min = 0.1;
+  o->ls_alpha_growth = 2.0;
   o->penalty_rho = 0.1;
   o->lambda_initial = 0.0;
   o->lambda_failure_init = 1.0e-2;
@@ -616,6 +617,7 @@ int orc_solve(const orc_opt_params* p, const orc_solver_opts* o_in, const double
 
   double lambda = o->lambda_initial;
   double mu = p->equality_penalty_initial;
+  double alpha_start = 1.0;
   int term = ORC_TERM_MAX_ITERATIONS;
   int iters = 0, ls_evals = 0, failed = 0;
   double f0 = 0.0, cn0 = 0.0, f_last = 0.0, cn_last = 0.0;
@@ -663,7 +665,7 @@ int orc_solve(const orc_opt_params* p, const orc_solver_opts* o_in, const double
     /* Armijo backtracking along the retraction; the next trial step is the minimiser of the
      * quadratic through phi(0), phi'(0), phi(alpha), safeguarded to [ls_shrink_min, ls_shrink_max]
      * times the current step */
-    double alpha = 1.0;
+    double alpha = alpha_start;
     int accepted = 0;
     double phi_t = 0.0, f_t = 0.0, cn_t = 0.0;
     for (int t = 0; t < o->max_line_search_iterations; ++t) {
@@ -684,6 +686,14 @@ int orc_solve(const orc_opt_params* p, const orc_solver_opts* o_in, const double
         if (a_new > o->ls_shrink_max * alpha) a_new = o->ls_shrink_max * alpha;
         alpha = a_new;
       }
+    }
+    /* step-length memory: after an accepted step the next line search starts from ls_alpha_growth
+     * times that step, capped at the full step; after a failed search (the damped direction will be
+     * a different one) it starts from the full step again; 0 disables (always start from 1) */
+    alpha_start = 1.0;
+    if (accepted && o->ls_alpha_growth > 0.0) {
+      alpha_start = o->ls_alpha_growth * alpha;
+      if (!(alpha_start < 1.0)) alpha_start = 1.0;
     }
     if (accepted) {
       memcpy(z, zt, sizeof(double) * (size_t)dim);

@@ -64,6 +64,7 @@ typedef struct orc_solver_opts {
   double armijo_c1;                   /* 1e-4 */
   double ls_shrink_max;               /* 0.5: upper safeguard of the interpolated step */
   double ls_shrink_min;               /* 0.1: lower safeguard */
+  double ls_alpha_growth;             /* 2: next search starts at min(1, this * last step); 0 = off */
   double penalty_rho;                 /* 0.1 */
   double lambda_initial;              /* 0 */
   double lambda_failure_init;         /* 1e-2 */
