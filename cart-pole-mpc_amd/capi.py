@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcpmpc.so")
+# CPMPC_LIB selects another build of the SAME library (kernel experiments); never a fallback
+LIB_PATH = os.environ.get("CPMPC_LIB") or os.path.join(_HERE, "lib", "libcpmpc.so")
 
 OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC, ERR_BATCH = range(7)
 F32, F64 = 0, 1

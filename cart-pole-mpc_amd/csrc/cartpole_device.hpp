@@ -21,6 +21,12 @@ struct Math;
 #ifndef CPMPC_F32_LIBM
 #define CPMPC_F32_LIBM 0  // 1: ocml sincosf/tanhf/sqrtf and IEEE division in the fp32 kernels
 #endif
+#ifndef CPMPC_F32_NATIVE_TRIG
+// 1 (default): v_sin_f32 / v_cos_f32.  Measured on MI355X: +13 % re-plans/s over the
+// polynomial below, and the fp32-vs-fp64 control error and the closed-loop balancing accuracy are the same
+// with either (fp32 rounding of the rest of the pipeline dominates).  0 selects the ~1-ulp polynomial.
+#define CPMPC_F32_NATIVE_TRIG 1
+#endif
 
 // fp32: the reference is fp64-only, so the fp32 kernels are free to use bounded-range routines.
 // Angles reaching sincos are at most a few turns (theta is wrapped to (-pi, pi] at every shooting node
@@ -36,6 +42,11 @@ struct Math<float> {
   static __device__ __forceinline__ float rcp(float x) { return 1.0f / x; }
 #else
   static __device__ __forceinline__ void sincos(float x, float& s, float& c) {
+#if CPMPC_F32_NATIVE_TRIG
+    s = __sinf(x);  // v_sin_f32 / v_cos_f32 on x/(2 pi); arguments here are at most a few turns
+    c = __cosf(x);
+    return;
+#endif
     const float kf = ::rintf(x * 0.63661977236758134f);  // nearest multiple of pi/2
     float r = ::fmaf(-kf, 1.5703125f, x);                // pi/2 split in three (Cody-Waite)
     r = ::fmaf(-kf, 4.837512969970703125e-4f, r);

@@ -370,7 +370,7 @@ __global__ __launch_bounds__(64) void qp_ls_kernel(const SolverArgs<R> a) {
 
   // ---- residuals at z: constraint l1 norm, a = dx_{S-1} for du = 0, terminal rows ---------------
   R f = R(0), cn = R(0);
-  R av[4], ci[4];
+  R ci[4];
   {
     const V4 z0 = a.zx[p];
     ci[0] = z0.x - xm[0];
@@ -378,22 +378,10 @@ __global__ __launch_bounds__(64) void qp_ls_kernel(const SolverArgs<R> a) {
     ci[2] = z0.z - xm[2];
     ci[3] = z0.w - xm[3];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      cn += Math<R>::fabs(ci[t]);
-      av[t] = -ci[t];
-    }
+    for (int t = 0; t < 4; ++t) cn += Math<R>::fabs(ci[t]);
   }
-  for (int s = 0; s + 1 < S; ++s) {
-    const V4 c = a.cs[(int64_t)s * st + p];
-    cn += Math<R>::fabs(c.x) + Math<R>::fabs(c.y) + Math<R>::fabs(c.z) + Math<R>::fabs(c.w);
-    R nv[4];
-    nv[0] = c.x + dot4<R>(a.Phi[(int64_t)(4 * s + 0) * st + p], av);
-    nv[1] = c.y + dot4<R>(a.Phi[(int64_t)(4 * s + 1) * st + p], av);
-    nv[2] = c.z + dot4<R>(a.Phi[(int64_t)(4 * s + 2) * st + p], av);
-    nv[3] = c.w + dot4<R>(a.Phi[(int64_t)(4 * s + 3) * st + p], av);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) av[t] = nv[t];
-  }
+  // The weighted free response  ha = diag(w) dx_{S-1}|_{du=0} = sum_s Psi_s c_s - Psi_{-1} c_init  is
+  // accumulated inside sweep 1, where Psi_s = diag(w) Phi_{S-2}...Phi_{s+1} is available anyway.
   R hv[4], Rw[4], Dg[4], e_term[4];
   {
     const V4 zT = a.zx[(int64_t)(S - 1) * st + p];
@@ -412,7 +400,7 @@ __global__ __launch_bounds__(64) void qp_ls_kernel(const SolverArgs<R> a) {
       } else {
         cn += Math<R>::fabs(d);
       }
-      hv[t] = Rw[t] * (d + av[t]);
+      hv[t] = Rw[t] * d;  // + ha[t], added after sweep 1
     }
   }
 
@@ -432,15 +420,25 @@ __global__ __launch_bounds__(64) void qp_ls_kernel(const SolverArgs<R> a) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) Psi[r][c] = (r == c) ? Rw[r] : R(0);
     R wprev[4] = {R(0), R(0), R(0), R(0)};
+    R ha[4] = {R(0), R(0), R(0), R(0)};
     R gwprev = R(0);
     R d_next = R(1);
-    R u_hi = R(0);                                    // u_{k+1}
-    R u_cur = a.zu[(int64_t)(N - 1) * st + p];        // u_k
+    const V4* __restrict__ gam_p = a.Gam + p;
+    const R* __restrict__ zu_p = a.zu + p;
+    R u_hi = R(0);                              // u_{k+1}
+    R u_cur = zu_p[(int64_t)(N - 1) * st];      // u_k
+    // software pipeline: the loads of column k-1 are issued before column k is consumed
+    V4 G_nx = gam_p[(int64_t)(N - 1) * st];
+    R u_nx = (N > 1) ? zu_p[(int64_t)(N - 2) * st] : u_prev;
     int kk = N - 1;
     for (int s = S - 2; s >= 0; --s) {
       for (int i = SP - 1; i >= 0; --i, --kk) {
-        const V4 G = a.Gam[(int64_t)kk * st + p];
-        const R u_lo = (kk > 0) ? a.zu[(int64_t)(kk - 1) * st + p] : u_prev;  // u_{k-1} (u_prev for k = 0)
+        const V4 G = G_nx;
+        const R u_lo = u_nx;  // u_{k-1} (u_prev for k = 0)
+        if (kk > 0) {
+          G_nx = gam_p[(int64_t)(kk - 1) * st];
+          u_nx = (kk > 1) ? zu_p[(int64_t)(kk - 2) * st] : u_prev;
+        }
         // control cost rows at z, tridiagonal entries and the control-cost gradient g_k
         const R ru = a.wu * u_cur, rd = a.wd * (u_lo - u_cur);
         f += ru * ru + rd * rd;
@@ -478,6 +476,13 @@ __global__ __launch_bounds__(64) void qp_ls_kernel(const SolverArgs<R> a) {
         u_hi = u_cur;
         u_cur = u_lo;
       }
+      // defect of this interval: |c|_1 and its weighted propagation to the last node, Psi_s c_s
+      {
+        const V4 c = a.cs[(int64_t)s * st + p];
+        cn += Math<R>::fabs(c.x) + Math<R>::fabs(c.y) + Math<R>::fabs(c.z) + Math<R>::fabs(c.w);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ha[r] += Psi[r][0] * c.x + Psi[r][1] * c.y + Psi[r][2] * c.z + Psi[r][3] * c.w;
+      }
       // Psi <- Psi Phi_s
       R Ph[4][4], T[4][4];
 #pragma unroll
@@ -498,6 +503,10 @@ __global__ __launch_bounds__(64) void qp_ls_kernel(const SolverArgs<R> a) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) Psi[r][c] = T[r][c];
     }
+    // Psi is now diag(w) Phi_{S-2}...Phi_0: contribution of dx_0 = -c_init
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      hv[r] += ha[r] - (Psi[r][0] * ci[0] + Psi[r][1] * ci[1] + Psi[r][2] * ci[2] + Psi[r][3] * ci[3]);
   }
   f *= R(0.5);
 
@@ -551,6 +560,10 @@ __global__ __launch_bounds__(64) void qp_ls_kernel(const SolverArgs<R> a) {
     a.dzx[p] = mk4<R>(dx[0], dx[1], dx[2], dx[3]);
     R du_prev = R(0);   // du_{k-1}; the (u_0 - u_prev) row sees only du_0
     R ups_prev = R(0);  // upsilon_{k-1}
+    const V4* __restrict__ w_p = a.Wk + p;
+    const V4* __restrict__ t_p = a.Tk + p;
+    const V4* __restrict__ g_p = a.Gam + p;
+    V4 W_nx = w_p[0], T_nx = t_p[0], G_nx = g_p[0];  // software pipeline, one column ahead
     int kk = 0;
     for (int s = 0; s + 1 < S; ++s) {
       const V4 c = a.cs[(int64_t)s * st + p];
@@ -560,9 +573,12 @@ __global__ __launch_bounds__(64) void qp_ls_kernel(const SolverArgs<R> a) {
       acc[2] = c.z + dot4<R>(a.Phi[(int64_t)(4 * s + 2) * st + p], dx);
       acc[3] = c.w + dot4<R>(a.Phi[(int64_t)(4 * s + 3) * st + p], dx);
       for (int i = 0; i < SP; ++i, ++kk) {
-        const V4 W = a.Wk[(int64_t)kk * st + p];
-        const V4 T = a.Tk[(int64_t)kk * st + p];
-        const V4 G = a.Gam[(int64_t)kk * st + p];
+        const V4 W = W_nx, T = T_nx, G = G_nx;
+        if (kk + 1 < N) {
+          W_nx = w_p[(int64_t)(kk + 1) * st];
+          T_nx = t_p[(int64_t)(kk + 1) * st];
+          G_nx = g_p[(int64_t)(kk + 1) * st];
+        }
         const R y = -(T.x + dot4<R>(W, q));
         const R du = y * T.z - ups_prev * du_prev;
         a.dzu[(int64_t)kk * st + p] = du;

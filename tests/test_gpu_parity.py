@@ -409,6 +409,28 @@ def test_full_size_properties_fp32(pkg, orc):
     assert np.median(err) < 5e-2
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.float64, 1e-6)])
+def test_closed_loop_balances(pkg, dtype, tol):
+    """Property at batch scale (the reference's closed-loop criterion, optimization_test.cc:63-66):
+    256 controllers from random near-upright states all end upright and still after 3 s, in fp32 too."""
+    rng = np.random.default_rng(3)
+    B = 256
+    x0 = np.stack([rng.uniform(-0.3, 0.3, B), np.pi / 2 + rng.uniform(-0.4, 0.4, B), rng.uniform(-0.5, 0.5, B),
+                   rng.uniform(-1, 1, B)])
+    opt = pkg.BatchOptimization(pkg.default_params(), max_batch=B, dtype=dtype, device=0)
+    sim = pkg.BatchSimulator(B, dtype=dtype, device=0)
+    sim.set_state(T(x0, dtype))
+    for _ in range(300):
+        out = opt.step(sim.get_state().clone(), DYN_UI, 0.0, want_predicted=False)
+        sim.step(DYN_UI, 0.01, out.u[0].contiguous())
+    s = N_(sim.get_state().double())
+    assert np.abs(s[1] - np.pi / 2).max() < tol and np.abs(s[0]).max() < tol
+    assert np.abs(s[2]).max() < 10 * tol and np.abs(s[3]).max() < 10 * tol
+    st = N_(out.status)
+    assert not np.isin(st, [pkg.capi.TERM["QP_INDEFINITE"], pkg.capi.TERM["MAX_LAMBDA"],
+                            pkg.capi.TERM["NON_FINITE"]]).any()
+
+
 def test_full_size_fp64_sample_parity(pkg, orc):
     """fp64 at B = 65536: lanes sampled across the batch agree with the oracle to 1e-5."""
     rng = np.random.default_rng(21)
