@@ -168,14 +168,20 @@ def main():
     roofline = {
         "bound": "valu", "kernel": dom, "achieved": round(achieved_tf, 3), "peak": peak_tf, "unit": "TFLOP/s",
         "frac": round(achieved_tf / peak_tf, 4), "traffic": traffic,
+        "traffic_GBps": (round(traffic / avg_s / 1e9, 1) if traffic else None),
+        "traffic_frac_of_hbm_peak": (round(traffic / avg_s / 1e9 / PEAK_HBM_GBPS, 4) if traffic else None),
         "avg_launch_ms": round(avg_s * 1e3, 4), "launches": int(dom_n),
         "algorithmic_flops_per_launch": flops_launch,
         "hbm": {"algorithmic_bytes_per_replan": bytes_replan,
                 "achieved_GBps": round(bytes_replan * value / world / 1e9, 3), "peak_GBps": PEAK_HBM_GBPS,
                 "frac": round(bytes_replan * value / world / 1e9 / PEAK_HBM_GBPS, 6)},
         "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in prof.items()},
-        "note": "the path is vector-ALU/transcendental bound (SURVEY.md 8d), neither HBM nor MFMA; "
-                "achieved = SURVEY 8(d) algorithmic flops of the dominant kernel / its HIP-event time",
+        "note": "the path as specified is vector-ALU/transcendental bound (SURVEY.md 8d), neither HBM nor MFMA: "
+                "achieved = SURVEY 8(d) algorithmic flops of the dominant kernel / its HIP-event time vs the "
+                "vector peak. `traffic` = HBM bytes per launch of that kernel from separate rocprofv3 --pmc "
+                "FETCH_SIZE / WRITE_SIZE passes (profiles/traffic_latest.json); it is the SQP workspace "
+                "(sensitivities, factors, step) streaming between kernels, not compulsory I/O, and "
+                "traffic_frac_of_hbm_peak says how close that streaming runs to the 8 TB/s peak",
     }
     line = {
         "metric": "MPC re-plans/sec (whole node), N=40 horizon, 5 SQP iters, batch 256k",
