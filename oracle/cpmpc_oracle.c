@@ -183,84 +183,211 @@ void orc_dynamics(const double params[9], const double x[4], double u, const dou
 }
 
 /* ------------------------------------------------------------------------------------------- */
+/* L0 (second model): cart + double pendulum                                                     */
+/* ------------------------------------------------------------------------------------------- */
+
+#include "double_pendulum_gen.inc" /* generated by tools/gen_dynamics.py */
+
+/* Solve the symmetric positive definite 3x3 system M y = b by LDL^T (M row-major). */
+static void spd3_factor(const double* M, double L[3], double d[3]) {
+  d[0] = M[0];
+  L[0] = M[3] / d[0];                       /* l10 */
+  L[1] = M[6] / d[0];                       /* l20 */
+  d[1] = M[4] - L[0] * L[0] * d[0];
+  L[2] = (M[7] - L[1] * L[0] * d[0]) / d[1]; /* l21 */
+  d[2] = M[8] - L[1] * L[1] * d[0] - L[2] * L[2] * d[1];
+}
+static void spd3_solve(const double L[3], const double d[3], const double b[3], double y[3]) {
+  const double z0 = b[0];
+  const double z1 = b[1] - L[0] * z0;
+  const double z2 = b[2] - L[1] * z0 - L[2] * z1;
+  y[2] = z2 / d[2];
+  y[1] = z1 / d[1] - L[2] * y[2];
+  y[0] = z0 / d[0] - L[0] * y[1] - L[1] * y[2];
+}
+
+/*
+ * Forward dynamics of the cart + two point-mass poles, specified by symbolic/dynamics_double.py:25-148
+ * (the reference ships no generated header for it and no optimizer: optimization.cc:197-199).
+ * x = {b_x, th_1, th_2, b_x', th_1', th_2'} (dynamics_double.py:117-118,136),
+ * params = {m_b, m_1, m_2, l_1, l_2, g} (dynamics_double.py:13-22); no dissipation, no external forces
+ * (f_base / f_mass are accepted for signature uniformity and ignored).
+ * a = M^-1 F;  da/dx_c = M^-1 (dF/dx_c - dM/dx_c a);  da/du = M^-1 e_0.
+ */
+void orc_dynamics_double(const double params[6], const double x[6], double u, const double f_base[2],
+                         const double f_mass[2], double f_out[6], double* Jx, double* Ju) {
+  (void)f_base;
+  (void)f_mass;
+  double M[9], F[3], dFdx[18], dM1[9], dM2[9], L[3], d[3], a[3];
+  double_pendulum_terms(params, x, u, M, F, dFdx, dM1, dM2);
+  spd3_factor(M, L, d);
+  spd3_solve(L, d, F, a);
+  f_out[0] = x[3];
+  f_out[1] = x[4];
+  f_out[2] = x[5];
+  f_out[3] = a[0];
+  f_out[4] = a[1];
+  f_out[5] = a[2];
+  if (Jx) {
+    for (int i = 0; i < 36; ++i) Jx[i] = 0.0;
+    Jx[0 * 6 + 3] = 1.0;
+    Jx[1 * 6 + 4] = 1.0;
+    Jx[2 * 6 + 5] = 1.0;
+    for (int c = 0; c < 6; ++c) {
+      double rhs[3], y[3];
+      for (int i = 0; i < 3; ++i) {
+        rhs[i] = dFdx[i * 6 + c];
+        const double* dM = (c == 1) ? dM1 : ((c == 2) ? dM2 : NULL);
+        if (dM)
+          for (int k = 0; k < 3; ++k) rhs[i] -= dM[i * 3 + k] * a[k];
+      }
+      spd3_solve(L, d, rhs, y);
+      for (int i = 0; i < 3; ++i) Jx[(3 + i) * 6 + c] = y[i];
+    }
+  }
+  if (Ju) {
+    const double e0[3] = {1.0, 0.0, 0.0};
+    double y[3];
+    spd3_solve(L, d, e0, y);
+    Ju[0] = Ju[1] = Ju[2] = 0.0;
+    Ju[3] = y[0];
+    Ju[4] = y[1];
+    Ju[5] = y[2];
+  }
+}
+
+/* total mechanical energy of the double pendulum (for the conservation test) */
+double orc_energy_double(const double params[6], const double x[6]) {
+  const double m_b = params[0], m_1 = params[1], m_2 = params[2], l_1 = params[3], l_2 = params[4], g = params[5];
+  const double s1 = sin(x[1]), c1 = cos(x[1]), s2 = sin(x[2]), c2 = cos(x[2]);
+  const double v = x[3], w1 = x[4], w2 = x[5];
+  const double p1x = v - l_1 * s1 * w1, p1y = l_1 * c1 * w1;
+  const double p2x = p1x - l_2 * s2 * w2, p2y = p1y + l_2 * c2 * w2;
+  const double T = 0.5 * m_b * v * v + 0.5 * m_1 * (p1x * p1x + p1y * p1y) + 0.5 * m_2 * (p2x * p2x + p2y * p2y);
+  const double V = g * m_1 * l_1 * s1 + g * m_2 * (l_1 * s1 + l_2 * s2);
+  return T + V;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* models                                                                                       */
+/* ------------------------------------------------------------------------------------------- */
+
+#define ORC_MAXNX 6
+typedef void (*orc_dyn_fn)(const double* p, const double* x, double u, const double* fb, const double* fm,
+                           double* f, double* Jx, double* Ju);
+typedef struct orc_model {
+  int nx;          /* state dimension: positions then velocities */
+  int nq;          /* nx / 2; component 0 is the base position, 1..nq-1 are pole angles */
+  int np;          /* number of dynamics parameters */
+  orc_dyn_fn dyn;
+} orc_model;
+
+static const orc_model kModels[2] = {
+    {4, 2, 9, (orc_dyn_fn)orc_dynamics},        /* ORC_MODEL_SINGLE */
+    {6, 3, 6, (orc_dyn_fn)orc_dynamics_double}, /* ORC_MODEL_DOUBLE */
+};
+static const orc_model* model_of(int id) { return (id == ORC_MODEL_DOUBLE) ? &kModels[1] : &kModels[0]; }
+static int is_angle(const orc_model* m, int t) { return t >= 1 && t < m->nq; }
+
+int orc_model_nx(int model) { return model_of(model)->nx; }
+int orc_model_np(int model) { return model_of(model)->np; }
+
+/* ------------------------------------------------------------------------------------------- */
 /* L1: integrators                                                                              */
 /* ------------------------------------------------------------------------------------------- */
 
-static void mat4_mul(const double* a, const double* b, double* out) { /* out = a*b, 4x4 */
-  double t[16];
-  for (int i = 0; i < 4; ++i)
-    for (int j = 0; j < 4; ++j) {
+static void mat_mul(int n, const double* a, const double* b, double* out) { /* out = a*b, n x n */
+  double t[ORC_MAXNX * ORC_MAXNX];
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) {
       double acc = 0.0;
-      for (int k = 0; k < 4; ++k) acc += a[i * 4 + k] * b[k * 4 + j];
-      t[i * 4 + j] = acc;
+      for (int k = 0; k < n; ++k) acc += a[i * n + k] * b[k * n + j];
+      t[i * n + j] = acc;
     }
-  memcpy(out, t, sizeof t);
+  memcpy(out, t, sizeof(double) * (size_t)(n * n));
 }
 
-static void mat4_vec(const double* a, const double* v, double* out) {
-  double t[4];
-  for (int i = 0; i < 4; ++i) {
+static void mat_vec(int n, const double* a, const double* v, double* out) {
+  double t[ORC_MAXNX];
+  for (int i = 0; i < n; ++i) {
     double acc = 0.0;
-    for (int k = 0; k < 4; ++k) acc += a[i * 4 + k] * v[k];
+    for (int k = 0; k < n; ++k) acc += a[i * n + k] * v[k];
     t[i] = acc;
   }
-  memcpy(out, t, sizeof t);
+  memcpy(out, t, sizeof(double) * (size_t)n);
 }
 
 /* optimization/integration.hpp:52-62 */
-void orc_rk4_no_jacobians(const double params[9], const double x[4], double u, double h,
-                          const double f_base[2], const double f_mass[2], double x_new[4]) {
-  double k1[4], k2[4], k3[4], k4[4], xt[4];
-  orc_dynamics(params, x, u, f_base, f_mass, k1, NULL, NULL);
-  for (int i = 0; i < 4; ++i) xt[i] = x[i] + k1[i] * h / 2.0;
-  orc_dynamics(params, xt, u, f_base, f_mass, k2, NULL, NULL);
-  for (int i = 0; i < 4; ++i) xt[i] = x[i] + k2[i] * h / 2.0;
-  orc_dynamics(params, xt, u, f_base, f_mass, k3, NULL, NULL);
-  for (int i = 0; i < 4; ++i) xt[i] = x[i] + k3[i] * h;
-  orc_dynamics(params, xt, u, f_base, f_mass, k4, NULL, NULL);
-  for (int i = 0; i < 4; ++i)
-    x_new[i] = x[i] + (h / 6.0) * (k1[i] + k2[i] * 2.0 + k3[i] * 2.0 + k4[i]);
+static void rk4_nj(const orc_model* m, const double* params, const double* x, double u, double h,
+                   const double* f_base, const double* f_mass, double* x_new) {
+  const int n = m->nx;
+  double k1[ORC_MAXNX], k2[ORC_MAXNX], k3[ORC_MAXNX], k4[ORC_MAXNX], xt[ORC_MAXNX];
+  m->dyn(params, x, u, f_base, f_mass, k1, NULL, NULL);
+  for (int i = 0; i < n; ++i) xt[i] = x[i] + k1[i] * h / 2.0;
+  m->dyn(params, xt, u, f_base, f_mass, k2, NULL, NULL);
+  for (int i = 0; i < n; ++i) xt[i] = x[i] + k2[i] * h / 2.0;
+  m->dyn(params, xt, u, f_base, f_mass, k3, NULL, NULL);
+  for (int i = 0; i < n; ++i) xt[i] = x[i] + k3[i] * h;
+  m->dyn(params, xt, u, f_base, f_mass, k4, NULL, NULL);
+  for (int i = 0; i < n; ++i) x_new[i] = x[i] + (h / 6.0) * (k1[i] + k2[i] * 2.0 + k3[i] * 2.0 + k4[i]);
 }
 
 /* optimization/integration.hpp:13-49: state + A = dx+/dx + B = dx+/du by the stage chain rule */
-void orc_rk4(const double params[9], const double x[4], double u, double h,
-             const double f_base[2], const double f_mass[2], double x_new[4], double A[16],
-             double B[4]) {
-  double k1[4], k2[4], k3[4], k4[4], xt[4];
-  double K1[16], K2[16], K3[16], K4[16]; /* stage Jacobians at the stage arguments */
-  double U1[4], U2[4], U3[4], U4[4];
-  orc_dynamics(params, x, u, f_base, f_mass, k1, K1, U1);
-  for (int i = 0; i < 4; ++i) xt[i] = x[i] + k1[i] * h / 2.0;
-  orc_dynamics(params, xt, u, f_base, f_mass, k2, K2, U2);
-  for (int i = 0; i < 4; ++i) xt[i] = x[i] + k2[i] * h / 2.0;
-  orc_dynamics(params, xt, u, f_base, f_mass, k3, K3, U3);
-  for (int i = 0; i < 4; ++i) xt[i] = x[i] + k3[i] * h;
-  orc_dynamics(params, xt, u, f_base, f_mass, k4, K4, U4);
-  for (int i = 0; i < 4; ++i)
-    x_new[i] = x[i] + (h / 6.0) * (k1[i] + k2[i] * 2.0 + k3[i] * 2.0 + k4[i]);
+static void rk4_j(const orc_model* m, const double* params, const double* x, double u, double h,
+                  const double* f_base, const double* f_mass, double* x_new, double* A, double* B) {
+  const int n = m->nx, nn = n * n;
+  double k1[ORC_MAXNX], k2[ORC_MAXNX], k3[ORC_MAXNX], k4[ORC_MAXNX], xt[ORC_MAXNX];
+  double K1[36], K2[36], K3[36], K4[36]; /* stage Jacobians at the stage arguments */
+  double U1[ORC_MAXNX], U2[ORC_MAXNX], U3[ORC_MAXNX], U4[ORC_MAXNX];
+  m->dyn(params, x, u, f_base, f_mass, k1, K1, U1);
+  for (int i = 0; i < n; ++i) xt[i] = x[i] + k1[i] * h / 2.0;
+  m->dyn(params, xt, u, f_base, f_mass, k2, K2, U2);
+  for (int i = 0; i < n; ++i) xt[i] = x[i] + k2[i] * h / 2.0;
+  m->dyn(params, xt, u, f_base, f_mass, k3, K3, U3);
+  for (int i = 0; i < n; ++i) xt[i] = x[i] + k3[i] * h;
+  m->dyn(params, xt, u, f_base, f_mass, k4, K4, U4);
+  for (int i = 0; i < n; ++i) x_new[i] = x[i] + (h / 6.0) * (k1[i] + k2[i] * 2.0 + k3[i] * 2.0 + k4[i]);
 
   /* integration.hpp:36-39: k2_D_x = K2 (I + K1 h/2), k3_D_x = K3 (I + k2_D_x h/2), ... */
-  double T[16], D2[16], D3[16], D4[16];
-  for (int i = 0; i < 16; ++i) T[i] = K1[i] * h / 2.0 + ((i % 5 == 0) ? 1.0 : 0.0);
-  mat4_mul(K2, T, D2);
-  for (int i = 0; i < 16; ++i) T[i] = D2[i] * h / 2.0 + ((i % 5 == 0) ? 1.0 : 0.0);
-  mat4_mul(K3, T, D3);
-  for (int i = 0; i < 16; ++i) T[i] = D3[i] * h + ((i % 5 == 0) ? 1.0 : 0.0);
-  mat4_mul(K4, T, D4);
+  double T[36], D2[36], D3[36], D4[36];
+  for (int i = 0; i < nn; ++i) T[i] = K1[i] * h / 2.0 + ((i % (n + 1) == 0) ? 1.0 : 0.0);
+  mat_mul(n, K2, T, D2);
+  for (int i = 0; i < nn; ++i) T[i] = D2[i] * h / 2.0 + ((i % (n + 1) == 0) ? 1.0 : 0.0);
+  mat_mul(n, K3, T, D3);
+  for (int i = 0; i < nn; ++i) T[i] = D3[i] * h + ((i % (n + 1) == 0) ? 1.0 : 0.0);
+  mat_mul(n, K4, T, D4);
 
   /* integration.hpp:41-43 */
-  double d2[4], d3[4], d4[4], t4[4];
-  mat4_vec(K2, U1, t4);
-  for (int i = 0; i < 4; ++i) d2[i] = t4[i] * (h / 2.0) + U2[i];
-  mat4_vec(K3, d2, t4);
-  for (int i = 0; i < 4; ++i) d3[i] = t4[i] * (h / 2.0) + U3[i];
-  mat4_vec(K4, d3, t4);
-  for (int i = 0; i < 4; ++i) d4[i] = t4[i] * h + U4[i];
+  double d2[ORC_MAXNX], d3[ORC_MAXNX], d4[ORC_MAXNX], tv[ORC_MAXNX];
+  mat_vec(n, K2, U1, tv);
+  for (int i = 0; i < n; ++i) d2[i] = tv[i] * (h / 2.0) + U2[i];
+  mat_vec(n, K3, d2, tv);
+  for (int i = 0; i < n; ++i) d3[i] = tv[i] * (h / 2.0) + U3[i];
+  mat_vec(n, K4, d3, tv);
+  for (int i = 0; i < n; ++i) d4[i] = tv[i] * h + U4[i];
 
   /* integration.hpp:45-46 */
-  for (int i = 0; i < 16; ++i)
-    A[i] = ((i % 5 == 0) ? 1.0 : 0.0) + (h / 6.0) * (K1[i] + D2[i] * 2.0 + D3[i] * 2.0 + D4[i]);
-  for (int i = 0; i < 4; ++i) B[i] = (h / 6.0) * (U1[i] + d2[i] * 2.0 + d3[i] * 2.0 + d4[i]);
+  for (int i = 0; i < nn; ++i)
+    A[i] = ((i % (n + 1) == 0) ? 1.0 : 0.0) + (h / 6.0) * (K1[i] + D2[i] * 2.0 + D3[i] * 2.0 + D4[i]);
+  for (int i = 0; i < n; ++i) B[i] = (h / 6.0) * (U1[i] + d2[i] * 2.0 + d3[i] * 2.0 + d4[i]);
+}
+
+void orc_rk4_no_jacobians(const double params[9], const double x[4], double u, double h,
+                          const double f_base[2], const double f_mass[2], double x_new[4]) {
+  rk4_nj(&kModels[0], params, x, u, h, f_base, f_mass, x_new);
+}
+void orc_rk4(const double params[9], const double x[4], double u, double h, const double f_base[2],
+             const double f_mass[2], double x_new[4], double A[16], double B[4]) {
+  rk4_j(&kModels[0], params, x, u, h, f_base, f_mass, x_new, A, B);
+}
+/* any model: A is nx x nx (nullable together with B -> Jacobian-free path) */
+void orc_rk4_model(int model, const double* params, const double* x, double u, double h, double* x_new,
+                   double* A, double* B) {
+  static const double z2[2] = {0.0, 0.0};
+  if (A && B)
+    rk4_j(model_of(model), params, x, u, h, z2, z2, x_new, A, B);
+  else
+    rk4_nj(model_of(model), params, x, u, h, z2, z2, x_new);
 }
 
 /* optimization/integration.hpp:65-73: map to (-pi, pi] */
@@ -279,79 +406,100 @@ double orc_mod_pi(double angle) {
 
 static const double kZero2[2] = {0.0, 0.0};
 
-/* optimization/optimization.cc:99-160.  The angle is wrapped only at the END of the interval here
- * (line 139), unlike FillInitialGuess / ComputePredictedStates which wrap after every step. */
-void orc_shooting_constraint(const double params[9], int spacing, double dt, const double* vars,
-                             double err[4], double* J) {
+/* optimization/optimization.cc:99-160.  The angles are wrapped only at the END of the interval here
+ * (line 139), unlike FillInitialGuess / ComputePredictedStates which wrap after every step.
+ * vars = [x_k(nx), x_k+1(nx), u(sp)];  J is nx x (2nx+sp) row-major = [Phi | -I | Gamma]. */
+static void shoot(const orc_model* m, const double* params, int spacing, double dt, const double* vars,
+                  double* err, double* J) {
+  const int n = m->nx;
   const double* x_k = vars;
-  const double* x_kp1 = vars + 4;
-  const double* u_k = vars + 8;
-  double x[4] = {x_k[0], x_k[1], x_k[2], x_k[3]};
+  const double* x_kp1 = vars + n;
+  const double* u_k = vars + 2 * n;
+  double x[ORC_MAXNX], xn[ORC_MAXNX];
+  memcpy(x, x_k, sizeof(double) * (size_t)n);
   double* As = NULL;
   double* Bs = NULL;
   if (J) {
-    As = (double*)malloc(sizeof(double) * 16 * (size_t)spacing);
-    Bs = (double*)malloc(sizeof(double) * 4 * (size_t)spacing);
+    As = (double*)malloc(sizeof(double) * (size_t)(n * n) * (size_t)spacing);
+    Bs = (double*)malloc(sizeof(double) * (size_t)n * (size_t)spacing);
     for (int i = 0; i < spacing; ++i) {
-      double xn[4];
-      orc_rk4(params, x, u_k[i], dt, kZero2, kZero2, xn, As + 16 * i, Bs + 4 * i);
-      memcpy(x, xn, sizeof xn);
+      rk4_j(m, params, x, u_k[i], dt, kZero2, kZero2, xn, As + n * n * i, Bs + n * i);
+      memcpy(x, xn, sizeof(double) * (size_t)n);
     }
   } else {
     for (int i = 0; i < spacing; ++i) {
-      double xn[4];
-      orc_rk4_no_jacobians(params, x, u_k[i], dt, kZero2, kZero2, xn);
-      memcpy(x, xn, sizeof xn);
+      rk4_nj(m, params, x, u_k[i], dt, kZero2, kZero2, xn);
+      memcpy(x, xn, sizeof(double) * (size_t)n);
     }
   }
-  x[1] = orc_mod_pi(x[1]);
+  for (int t = 0; t < n; ++t)
+    if (is_angle(m, t)) x[t] = orc_mod_pi(x[t]);
 
   if (J) {
-    const int cols = 8 + spacing;
-    double Phi[16];
-    for (int i = 0; i < 16; ++i) Phi[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    const int cols = 2 * n + spacing;
+    double Phi[36];
+    for (int i = 0; i < n * n; ++i) Phi[i] = (i % (n + 1) == 0) ? 1.0 : 0.0;
     /* optimization.cc:145-151: backward chain rule */
     for (int i = spacing - 1; i >= 0; --i) {
-      double g4[4];
-      mat4_vec(Phi, Bs + 4 * i, g4);
-      for (int r = 0; r < 4; ++r) J[r * cols + 8 + i] = g4[r];
-      mat4_mul(Phi, As + 16 * i, Phi);
+      double gv[ORC_MAXNX];
+      mat_vec(n, Phi, Bs + n * i, gv);
+      for (int r = 0; r < n; ++r) J[r * cols + 2 * n + i] = gv[r];
+      mat_mul(n, Phi, As + n * n * i, Phi);
     }
-    for (int r = 0; r < 4; ++r)
-      for (int cI = 0; cI < 4; ++cI) {
-        J[r * cols + cI] = Phi[r * 4 + cI];
-        J[r * cols + 4 + cI] = (r == cI) ? -1.0 : 0.0;
+    for (int r = 0; r < n; ++r)
+      for (int cI = 0; cI < n; ++cI) {
+        J[r * cols + cI] = Phi[r * n + cI];
+        J[r * cols + n + cI] = (r == cI) ? -1.0 : 0.0;
       }
     free(As);
     free(Bs);
   }
-  for (int i = 0; i < 4; ++i) err[i] = x[i] - x_kp1[i];
-  err[1] = orc_mod_pi(err[1]);
+  for (int i = 0; i < n; ++i) err[i] = x[i] - x_kp1[i];
+  for (int t = 0; t < n; ++t)
+    if (is_angle(m, t)) err[t] = orc_mod_pi(err[t]);
+}
+
+void orc_shooting_constraint(const double params[9], int spacing, double dt, const double* vars,
+                             double err[4], double* J) {
+  shoot(&kModels[0], params, spacing, dt, vars, err, J);
+}
+void orc_shooting_constraint_model(int model, const double* params, int spacing, double dt, const double* vars,
+                                   double* err, double* J) {
+  shoot(model_of(model), params, spacing, dt, vars, err, J);
 }
 
 static int num_states(const orc_opt_params* p) { /* optimization.hpp:52 */
   return (int)(p->window_length / p->state_spacing) + 1;
 }
 
-/* terminal weights in BuildProblem order (optimization.cc:236-267) */
-static void terminal_spec(const orc_opt_params* p, double set_point, double w[4], double tgt[4]) {
-  w[0] = p->b_x_final_cost_weight;
-  w[1] = p->th_final_cost_weight;
-  w[2] = p->b_x_dot_final_cost_weight;
-  w[3] = p->th_dot_final_cost_weight;
-  tgt[0] = set_point;
-  tgt[1] = M_PI / 2;
-  tgt[2] = 0.0;
-  tgt[3] = 0.0;
+/* Terminal weights and targets in BuildProblem order (optimization.cc:236-267).  For the double pendulum
+ * (no optimizer in the reference) th_final / th_dot_final apply to both poles and both are to be upright. */
+static void terminal_spec(const orc_model* m, const orc_opt_params* p, double set_point, double* w, double* tgt) {
+  for (int t = 0; t < m->nx; ++t) {
+    if (t == 0) {
+      w[t] = p->b_x_final_cost_weight;
+      tgt[t] = set_point;
+    } else if (t < m->nq) {
+      w[t] = p->th_final_cost_weight;
+      tgt[t] = M_PI / 2;
+    } else if (t == m->nq) {
+      w[t] = p->b_x_dot_final_cost_weight;
+      tgt[t] = 0.0;
+    } else {
+      w[t] = p->th_dot_final_cost_weight;
+      tgt[t] = 0.0;
+    }
+  }
 }
 
-void orc_problem_shape(const orc_opt_params* p, int* dim, int* n_eq, int* n_cost) {
+static void problem_shape(const orc_model* m, const orc_opt_params* p, int* dim, int* n_eq, int* n_cost) {
   const int S = num_states(p);
   const int N = (int)p->window_length;
-  double w[4], tgt[4];
-  terminal_spec(p, 0.0, w, tgt);
-  int ne = 4 * (S - 1) + 4, nc = 0;
-  for (int t = 0; t < 4; ++t) {
+  const int n = m->nx;
+  double w[ORC_MAXNX], tgt[ORC_MAXNX];
+  terminal_spec(m, p, 0.0, w, tgt);
+  int ne = n * (S - 1) + n, nc = 0;
+  for (int t = 0; t < n; ++t) {
     if (w[t] >= 0.0)
       ++nc;
     else
@@ -359,69 +507,78 @@ void orc_problem_shape(const orc_opt_params* p, int* dim, int* n_eq, int* n_cost
   }
   if (p->u_derivative_cost_weight > 0.0) nc += (N - 1) + 1;
   if (p->u_cost_weight > 0.0) nc += N;
-  if (dim) *dim = 4 * S + N; /* optimization.cc:204-205 */
+  if (dim) *dim = n * S + N; /* optimization.cc:204-205 */
   if (n_eq) *n_eq = ne;
   if (n_cost) *n_cost = nc;
 }
 
+void orc_problem_shape(const orc_opt_params* p, int* dim, int* n_eq, int* n_cost) {
+  problem_shape(&kModels[0], p, dim, n_eq, n_cost);
+}
+void orc_problem_shape_model(int model, const orc_opt_params* p, int* dim, int* n_eq, int* n_cost) {
+  problem_shape(model_of(model), p, dim, n_eq, n_cost);
+}
+
 /* optimization/optimization.cc:194-301 (BuildProblem) evaluated at z.
- * Variable layout (MapKey, optimization.cc:27-37): state t of shooting node s at 4s+t, u_k at 4S+k. */
-void orc_problem_eval(const orc_opt_params* p, const double dyn[9], const double x_current[4],
-                      double set_point, double u_prev, const double* z, double* r_cost,
-                      double* c_eq, double* J_cost, double* A_eq) {
+ * Variable layout (MapKey<StateDim>, optimization.cc:27-37): state t of node s at nx*s+t, u_k at nx*S+k. */
+static void problem_eval(const orc_model* m, const orc_opt_params* p, const double* dyn, const double* x_current,
+                         double set_point, double u_prev, const double* z, double* r_cost, double* c_eq,
+                         double* J_cost, double* A_eq) {
   const int S = num_states(p);
   const int N = (int)p->window_length;
   const int sp = (int)p->state_spacing;
+  const int n = m->nx;
   int dim, n_eq, n_cost;
-  orc_problem_shape(p, &dim, &n_eq, &n_cost);
+  problem_shape(m, p, &dim, &n_eq, &n_cost);
   if (J_cost) memset(J_cost, 0, sizeof(double) * (size_t)n_cost * (size_t)dim);
   if (A_eq) memset(A_eq, 0, sizeof(double) * (size_t)n_eq * (size_t)dim);
 
   int re = 0, rc = 0;
-  double* vars = (double*)malloc(sizeof(double) * (size_t)(8 + sp));
-  double* Jloc = A_eq ? (double*)malloc(sizeof(double) * 4 * (size_t)(8 + sp)) : NULL;
+  const int nv = 2 * n + sp;
+  double* vars = (double*)malloc(sizeof(double) * (size_t)nv);
+  double* Jloc = A_eq ? (double*)malloc(sizeof(double) * (size_t)n * (size_t)nv) : NULL;
 
   /* shooting equality constraints between adjacent states (optimization.cc:208-225) */
   for (int s = 0; s + 1 < S; ++s) {
-    for (int t = 0; t < 4; ++t) {
-      vars[t] = z[4 * s + t];
-      vars[4 + t] = z[4 * (s + 1) + t];
+    for (int t = 0; t < n; ++t) {
+      vars[t] = z[n * s + t];
+      vars[n + t] = z[n * (s + 1) + t];
     }
-    for (int k = 0; k < sp; ++k) vars[8 + k] = z[4 * S + sp * s + k];
-    double err[4];
-    orc_shooting_constraint(dyn, sp, p->control_dt, vars, err, Jloc);
-    for (int r = 0; r < 4; ++r) {
+    for (int k = 0; k < sp; ++k) vars[2 * n + k] = z[n * S + sp * s + k];
+    double err[ORC_MAXNX];
+    shoot(m, dyn, sp, p->control_dt, vars, err, Jloc);
+    for (int r = 0; r < n; ++r) {
       c_eq[re + r] = err[r];
       if (A_eq) {
         double* row = A_eq + (size_t)(re + r) * dim;
-        for (int t = 0; t < 4; ++t) {
-          row[4 * s + t] = Jloc[r * (8 + sp) + t];
-          row[4 * (s + 1) + t] = Jloc[r * (8 + sp) + 4 + t];
+        for (int t = 0; t < n; ++t) {
+          row[n * s + t] = Jloc[r * nv + t];
+          row[n * (s + 1) + t] = Jloc[r * nv + n + t];
         }
-        for (int k = 0; k < sp; ++k) row[4 * S + sp * s + k] = Jloc[r * (8 + sp) + 8 + k];
+        for (int k = 0; k < sp; ++k) row[n * S + sp * s + k] = Jloc[r * nv + 2 * n + k];
       }
     }
-    re += 4;
+    re += n;
   }
   free(vars);
   free(Jloc);
 
-  /* equality constraint on the initial state, weight 1, angle wrapped (optimization.cc:228-232) */
-  for (int t = 0; t < 4; ++t) {
+  /* equality constraint on the initial state, weight 1, angles wrapped (optimization.cc:228-232) */
+  for (int t = 0; t < n; ++t) {
     double d = z[t] - x_current[t];
-    if (t == 1) d = orc_mod_pi(d);
+    if (is_angle(m, t)) d = orc_mod_pi(d);
     c_eq[re] = d * 1.0;
     if (A_eq) A_eq[(size_t)re * dim + t] = 1.0;
     ++re;
   }
 
   /* terminal rows: cost if weight >= 0 else equality with weight 1 (optimization.cc:236-267) */
-  double w[4], tgt[4];
-  terminal_spec(p, set_point, w, tgt);
-  for (int t = 0; t < 4; ++t) {
-    const int idx = 4 * (S - 1) + t;
+  double w[ORC_MAXNX], tgt[ORC_MAXNX];
+  terminal_spec(m, p, set_point, w, tgt);
+  for (int t = 0; t < n; ++t) {
+    const int idx = n * (S - 1) + t;
     double d = z[idx] - tgt[t];
-    if (t == 1) d = orc_mod_pi(d);
+    if (is_angle(m, t)) d = orc_mod_pi(d);
     if (w[t] >= 0.0) {
       r_cost[rc] = d * w[t];
       if (J_cost) J_cost[(size_t)rc * dim + idx] = w[t];
@@ -437,42 +594,54 @@ void orc_problem_eval(const orc_opt_params* p, const double dyn[9], const double
   if (p->u_derivative_cost_weight > 0.0) {
     const double wd = p->u_derivative_cost_weight;
     for (int k = 0; k + 1 < N; ++k) {
-      r_cost[rc] = (z[4 * S + k] - z[4 * S + k + 1]) * wd;
+      r_cost[rc] = (z[n * S + k] - z[n * S + k + 1]) * wd;
       if (J_cost) {
-        J_cost[(size_t)rc * dim + 4 * S + k] = wd;
-        J_cost[(size_t)rc * dim + 4 * S + k + 1] = -wd;
+        J_cost[(size_t)rc * dim + n * S + k] = wd;
+        J_cost[(size_t)rc * dim + n * S + k + 1] = -wd;
       }
       ++rc;
     }
-    r_cost[rc] = (z[4 * S + 0] - u_prev) * wd;
-    if (J_cost) J_cost[(size_t)rc * dim + 4 * S + 0] = wd;
+    r_cost[rc] = (z[n * S + 0] - u_prev) * wd;
+    if (J_cost) J_cost[(size_t)rc * dim + n * S + 0] = wd;
     ++rc;
   }
   /* penalty on the control inputs (optimization.cc:296-301) */
   if (p->u_cost_weight > 0.0) {
     const double wu = p->u_cost_weight;
     for (int k = 0; k < N; ++k) {
-      r_cost[rc] = (z[4 * S + k] - 0.0) * wu;
-      if (J_cost) J_cost[(size_t)rc * dim + 4 * S + k] = wu;
+      r_cost[rc] = (z[n * S + k] - 0.0) * wu;
+      if (J_cost) J_cost[(size_t)rc * dim + n * S + k] = wu;
       ++rc;
     }
   }
 }
 
+void orc_problem_eval(const orc_opt_params* p, const double dyn[9], const double x_current[4],
+                      double set_point, double u_prev, const double* z, double* r_cost, double* c_eq,
+                      double* J_cost, double* A_eq) {
+  problem_eval(&kModels[0], p, dyn, x_current, set_point, u_prev, z, r_cost, c_eq, J_cost, A_eq);
+}
+
 static double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 /* optimization/optimization.cc:309-329 */
-void orc_retract(const orc_opt_params* p, const orc_solver_opts* o, const double* z,
-                 const double* dz, double alpha, double* z_out) {
+static void retract(const orc_model* m, const orc_opt_params* p, const orc_solver_opts* o, const double* z,
+                    const double* dz, double alpha, double* z_out) {
   const int S = num_states(p);
   const int N = (int)p->window_length;
-  const int dim = 4 * S + N;
+  const int n = m->nx;
+  const int dim = n * S + N;
   for (int i = 0; i < dim; ++i) z_out[i] = z[i] + dz[i] * alpha;
   for (int s = 0; s < S; ++s) {
-    z_out[4 * s + 1] = orc_mod_pi(z_out[4 * s + 1]);
-    z_out[4 * s + 0] = clampd(z_out[4 * s + 0], -o->b_x_limit, o->b_x_limit);
+    for (int t = 1; t < m->nq; ++t) z_out[n * s + t] = orc_mod_pi(z_out[n * s + t]);
+    z_out[n * s + 0] = clampd(z_out[n * s + 0], -o->b_x_limit, o->b_x_limit);
   }
-  for (int k = 0; k < N; ++k) z_out[4 * S + k] = clampd(z_out[4 * S + k], -o->u_limit, o->u_limit);
+  for (int k = 0; k < N; ++k) z_out[n * S + k] = clampd(z_out[n * S + k], -o->u_limit, o->u_limit);
+}
+
+void orc_retract(const orc_opt_params* p, const orc_solver_opts* o, const double* z, const double* dz,
+                 double alpha, double* z_out) {
+  retract(&kModels[0], p, o, z, dz, alpha, z_out);
 }
 
 /* ------------------------------------------------------------------------------------------- */
@@ -591,9 +760,9 @@ static double l1_norm(const double* v, int n) {
  *   retraction -> accept (decay lambda) or reject (raise lambda); exits on first-order tolerance,
  *   relative decrease, QP failure, lambda overflow, or max_iterations.
  */
-int orc_solve(const orc_opt_params* p, const orc_solver_opts* o_in, const double dyn[9],
-              const double x_current[4], double set_point, double u_prev, const double* guess,
-              double* z_out, orc_solver_summary* summary) {
+static int solve(const orc_model* m, const orc_opt_params* p, const orc_solver_opts* o_in, const double* dyn,
+                 const double* x_current, double set_point, double u_prev, const double* guess, double* z_out,
+                 orc_solver_summary* summary) {
   orc_solver_opts o_def;
   if (!o_in) {
     orc_default_solver_opts(&o_def);
@@ -601,7 +770,7 @@ int orc_solve(const orc_opt_params* p, const orc_solver_opts* o_in, const double
   }
   const orc_solver_opts* o = o_in;
   int dim, n_eq, n_cost;
-  orc_problem_shape(p, &dim, &n_eq, &n_cost);
+  problem_shape(m, p, &dim, &n_eq, &n_cost);
   const int N = (int)p->window_length;
 
   double* z = (double*)malloc(sizeof(double) * (size_t)dim);
@@ -623,7 +792,7 @@ int orc_solve(const orc_opt_params* p, const orc_solver_opts* o_in, const double
   double f0 = 0.0, cn0 = 0.0, f_last = 0.0, cn_last = 0.0;
 
   for (int iter = 0; iter < (int)p->max_iterations; ++iter) {
-    orc_problem_eval(p, dyn, x_current, set_point, u_prev, z, r, c, J, A);
+    problem_eval(m, p, dyn, x_current, set_point, u_prev, z, r, c, J, A);
     const double f = half_sq_norm(r, n_cost);
     const double cn = l1_norm(c, n_eq);
     if (iter == 0) {
@@ -669,8 +838,8 @@ int orc_solve(const orc_opt_params* p, const orc_solver_opts* o_in, const double
     int accepted = 0;
     double phi_t = 0.0, f_t = 0.0, cn_t = 0.0;
     for (int t = 0; t < o->max_line_search_iterations; ++t) {
-      orc_retract(p, o, z, dz, alpha, zt);
-      orc_problem_eval(p, dyn, x_current, set_point, u_prev, zt, rt, ct, NULL, NULL);
+      retract(m, p, o, z, dz, alpha, zt);
+      problem_eval(m, p, dyn, x_current, set_point, u_prev, zt, rt, ct, NULL, NULL);
       ++ls_evals;
       f_t = half_sq_norm(rt, n_cost);
       cn_t = l1_norm(ct, n_eq);
@@ -746,6 +915,12 @@ int orc_solve(const orc_opt_params* p, const orc_solver_opts* o_in, const double
   return 0;
 }
 
+int orc_solve(const orc_opt_params* p, const orc_solver_opts* o_in, const double dyn[9],
+              const double x_current[4], double set_point, double u_prev, const double* guess,
+              double* z_out, orc_solver_summary* summary) {
+  return solve(&kModels[0], p, o_in, dyn, x_current, set_point, u_prev, guess, z_out, summary);
+}
+
 /* ------------------------------------------------------------------------------------------- */
 /* L3: Optimization::Step                                                                       */
 /* ------------------------------------------------------------------------------------------- */
@@ -753,13 +928,14 @@ int orc_solve(const orc_opt_params* p, const orc_solver_opts* o_in, const double
 struct orc_optimization {
   orc_opt_params params;
   orc_solver_opts opts;
+  const orc_model* model;
   int has_prev;
   int dim;
   double* prev; /* previous_solution_ (optimization.hpp:107) */
 };
 
 /* optimization/optimization.cc:13-22: the constructor's preconditions */
-orc_optimization* orc_opt_create(const orc_opt_params* p, const orc_solver_opts* o) {
+orc_optimization* orc_opt_create_model(const orc_opt_params* p, const orc_solver_opts* o, int model) {
   if (!(p->control_dt > 0)) return NULL;
   if (!(p->window_length >= 1)) return NULL;
   if (p->state_spacing == 0 || p->window_length % p->state_spacing != 0) return NULL;
@@ -772,10 +948,14 @@ orc_optimization* orc_opt_create(const orc_opt_params* p, const orc_solver_opts*
     opt->opts = *o;
   else
     orc_default_solver_opts(&opt->opts);
-  orc_problem_shape(p, &opt->dim, NULL, NULL);
+  opt->model = model_of(model);
+  problem_shape(opt->model, p, &opt->dim, NULL, NULL);
   opt->prev = (double*)calloc((size_t)opt->dim, sizeof(double));
   opt->has_prev = 0;
   return opt;
+}
+orc_optimization* orc_opt_create(const orc_opt_params* p, const orc_solver_opts* o) {
+  return orc_opt_create_model(p, o, ORC_MODEL_SINGLE);
 }
 
 void orc_opt_destroy(orc_optimization* opt) {
@@ -797,12 +977,15 @@ void orc_opt_set_previous_solution(orc_optimization* opt, const double* z, int n
 }
 
 int orc_opt_has_previous_solution(const orc_optimization* opt) { return opt->has_prev; }
+int orc_opt_dim(const orc_optimization* opt) { return opt->dim; }
 
-/* optimization/optimization.cc:39-97 */
-int orc_opt_step(orc_optimization* opt, const double state[4], const double dyn[9],
-                 double set_point, double* u_out, double* predicted_out, double* guess_out,
-                 double* z_out, orc_solver_summary* summary) {
+/* optimization/optimization.cc:39-97.  state[nx], dyn[np]; predicted_out[N*nx]. */
+int orc_opt_step(orc_optimization* opt, const double* state, const double* dyn, double set_point,
+                 double* u_out, double* predicted_out, double* guess_out, double* z_out,
+                 orc_solver_summary* summary) {
   const orc_opt_params* p = &opt->params;
+  const orc_model* m = opt->model;
+  const int n = m->nx;
   const int S = num_states(p);
   const int N = (int)p->window_length;
   const int sp = (int)p->state_spacing;
@@ -810,56 +993,54 @@ int orc_opt_step(orc_optimization* opt, const double state[4], const double dyn[
 
   /* BuildProblem runs first and reads u_prev from the not-yet-overwritten previous solution
    * (optimization.cc:44,288-291) */
-  const double u_prev = opt->has_prev ? opt->prev[4 * S + 0] : 0.0;
+  const double u_prev = opt->has_prev ? opt->prev[n * S + 0] : 0.0;
 
   double* guess = (double*)calloc((size_t)dim, sizeof(double));
   if (opt->has_prev) {
     /* optimization.cc:50-57: copy, overwrite x0, shift controls left by one */
     memcpy(guess, opt->prev, sizeof(double) * (size_t)dim);
-    for (int t = 0; t < 4; ++t) guess[t] = state[t];
-    for (int k = 0; k + 1 < N; ++k) guess[4 * S + k] = guess[4 * S + k + 1];
+    for (int t = 0; t < n; ++t) guess[t] = state[t];
+    for (int k = 0; k + 1 < N; ++k) guess[n * S + k] = guess[n * S + k + 1];
   } else {
     /* optimization.cc:58-68: sinusoid control guess */
-    for (int t = 0; t < 4; ++t) guess[t] = state[t];
+    for (int t = 0; t < n; ++t) guess[t] = state[t];
     for (int k = 0; k < N; ++k)
-      guess[4 * S + k] =
-          p->u_guess_sinusoid_amplitude * sin((double)k / (double)N * 2 * M_PI);
+      guess[n * S + k] = p->u_guess_sinusoid_amplitude * sin((double)k / (double)N * 2 * M_PI);
   }
   /* FillInitialGuess, optimization.cc:333-351: roll the states, wrapping after EVERY step */
   {
-    double x[4] = {guess[0], guess[1], guess[2], guess[3]};
+    double x[ORC_MAXNX], xn[ORC_MAXNX];
+    memcpy(x, guess, sizeof(double) * (size_t)n);
     for (int s = 1; s < S; ++s) {
       for (int k = 0; k < sp; ++k) {
-        double xn[4];
-        orc_rk4_no_jacobians(dyn, x, guess[4 * S + (s - 1) * sp + k], p->control_dt, kZero2,
-                             kZero2, xn);
-        memcpy(x, xn, sizeof xn);
-        x[1] = orc_mod_pi(x[1]);
+        rk4_nj(m, dyn, x, guess[n * S + (s - 1) * sp + k], p->control_dt, kZero2, kZero2, xn);
+        memcpy(x, xn, sizeof(double) * (size_t)n);
+        for (int t = 1; t < m->nq; ++t) x[t] = orc_mod_pi(x[t]);
       }
-      for (int t = 0; t < 4; ++t) guess[4 * s + t] = x[t];
+      for (int t = 0; t < n; ++t) guess[n * s + t] = x[t];
     }
   }
   if (guess_out) memcpy(guess_out, guess, sizeof(double) * (size_t)dim);
 
   double* z = (double*)malloc(sizeof(double) * (size_t)dim);
-  orc_solve(p, &opt->opts, dyn, state, set_point, u_prev, guess, z, summary);
+  solve(m, p, &opt->opts, dyn, state, set_point, u_prev, guess, z, summary);
 
   /* optimization.cc:85 */
   memcpy(opt->prev, z, sizeof(double) * (size_t)dim);
   opt->has_prev = 1;
 
   if (u_out)
-    for (int k = 0; k < N; ++k) u_out[k] = z[4 * S + k]; /* optimization.cc:88-89 */
+    for (int k = 0; k < N; ++k) u_out[k] = z[n * S + k]; /* optimization.cc:88-89 */
 
   /* ComputePredictedStates, optimization.cc:353-371 */
   if (predicted_out) {
-    double x[4] = {state[0], state[1], state[2], state[3]};
+    double x[ORC_MAXNX], xn[ORC_MAXNX];
+    memcpy(x, state, sizeof(double) * (size_t)n);
     for (int k = 0; k < N; ++k) {
-      double xn[4];
-      orc_rk4_no_jacobians(dyn, x, z[4 * S + k], p->control_dt, kZero2, kZero2, xn);
-      memcpy(x, xn, sizeof xn);
-      x[1] = orc_mod_pi(x[1]);
-      for (int t = 0; t < 4; ++t) predicted_out[4 * k + t] = x[t];
+      rk4_nj(m, dyn, x, z[n * S + k], p->control_dt, kZero2, kZero2, xn);
+      memcpy(x, xn, sizeof(double) * (size_t)n);
+      for (int t = 1; t < m->nq; ++t) x[t] = orc_mod_pi(x[t]);
+      for (int t = 0; t < n; ++t) predicted_out[n * k + t] = x[t];
     }
   }
   if (z_out) memcpy(z_out, z, sizeof(double) * (size_t)dim);
@@ -872,28 +1053,36 @@ int orc_opt_step(orc_optimization* opt, const double state[4], const double dyn[
 /* Simulator                                                                                    */
 /* ------------------------------------------------------------------------------------------- */
 
-/* optimization/simulator.cc:11-36: fixed 1 ms sub-steps, angle wrapped after each */
-void orc_sim_step(const double params[9], double dt, double u, const double f_base[2],
-                  const double f_mass[2], double state[4]) {
+/* optimization/simulator.cc:11-36: fixed 1 ms sub-steps, angles wrapped after each */
+static void sim_step(const orc_model* m, const double* params, double dt, double u, const double* f_base,
+                     const double* f_mass, double* state) {
   const double internal_dt = 0.001;
   while (dt > 0.0) {
     const double h = dt < internal_dt ? dt : internal_dt;
-    double xn[4];
-    orc_rk4_no_jacobians(params, state, u, h, f_base, f_mass, xn);
-    memcpy(state, xn, sizeof xn);
-    state[1] = orc_mod_pi(state[1]);
+    double xn[ORC_MAXNX];
+    rk4_nj(m, params, state, u, h, f_base, f_mass, xn);
+    memcpy(state, xn, sizeof(double) * (size_t)m->nx);
+    for (int t = 1; t < m->nq; ++t) state[t] = orc_mod_pi(state[t]);
     dt -= internal_dt;
   }
+}
+void orc_sim_step(const double params[9], double dt, double u, const double f_base[2], const double f_mass[2],
+                  double state[4]) {
+  sim_step(&kModels[0], params, dt, u, f_base, f_mass, state);
+}
+void orc_sim_step_model(int model, const double* params, double dt, double u, double* state) {
+  sim_step(model_of(model), params, dt, u, kZero2, kZero2, state);
 }
 
 /* ------------------------------------------------------------------------------------------- */
 /* batch driver                                                                                 */
 /* ------------------------------------------------------------------------------------------- */
 
-int orc_step_batch_cold(const orc_opt_params* p, const orc_solver_opts* o, const double dyn[9],
-                        double set_point, int64_t B, const double* x0_soa, double* u_out_soa,
-                        double* pred_out_soa, int32_t* status, int32_t* iters, int num_threads) {
+int orc_step_batch_cold_model(int model, const orc_opt_params* p, const orc_solver_opts* o, const double* dyn,
+                              double set_point, int64_t B, const double* x0_soa, double* u_out_soa,
+                              double* pred_out_soa, int32_t* status, int32_t* iters, int num_threads) {
   const int N = (int)p->window_length;
+  const int n = model_of(model)->nx;
   int used = 1;
 #ifdef _OPENMP
   if (num_threads > 0) omp_set_num_threads(num_threads);
@@ -903,21 +1092,21 @@ int orc_step_batch_cold(const orc_opt_params* p, const orc_solver_opts* o, const
 #endif
 #pragma omp parallel
   {
-    orc_optimization* opt = orc_opt_create(p, o);
+    orc_optimization* opt = orc_opt_create_model(p, o, model);
     double* u = (double*)malloc(sizeof(double) * (size_t)N);
-    double* pred = (double*)malloc(sizeof(double) * 4 * (size_t)N);
+    double* pred = (double*)malloc(sizeof(double) * (size_t)n * (size_t)N);
 #pragma omp for schedule(dynamic, 16)
     for (int64_t b = 0; b < B; ++b) {
       if (!opt) continue;
       orc_opt_reset(opt);
-      const double x0[4] = {x0_soa[0 * B + b], x0_soa[1 * B + b], x0_soa[2 * B + b],
-                            x0_soa[3 * B + b]};
+      double x0[ORC_MAXNX];
+      for (int t = 0; t < n; ++t) x0[t] = x0_soa[(int64_t)t * B + b];
       orc_solver_summary sum;
       orc_opt_step(opt, x0, dyn, set_point, u, pred_out_soa ? pred : NULL, NULL, NULL, &sum);
       for (int k = 0; k < N; ++k) u_out_soa[(int64_t)k * B + b] = u[k];
       if (pred_out_soa)
         for (int k = 0; k < N; ++k)
-          for (int t = 0; t < 4; ++t) pred_out_soa[((int64_t)k * 4 + t) * B + b] = pred[4 * k + t];
+          for (int t = 0; t < n; ++t) pred_out_soa[((int64_t)k * n + t) * B + b] = pred[n * k + t];
       if (status) status[b] = sum.termination_state;
       if (iters) iters[b] = sum.iterations;
     }
@@ -926,4 +1115,11 @@ int orc_step_batch_cold(const orc_opt_params* p, const orc_solver_opts* o, const
     orc_opt_destroy(opt);
   }
   return used;
+}
+
+int orc_step_batch_cold(const orc_opt_params* p, const orc_solver_opts* o, const double dyn[9],
+                        double set_point, int64_t B, const double* x0_soa, double* u_out_soa,
+                        double* pred_out_soa, int32_t* status, int32_t* iters, int num_threads) {
+  return orc_step_batch_cold_model(ORC_MODEL_SINGLE, p, o, dyn, set_point, B, x0_soa, u_out_soa, pred_out_soa,
+                                   status, iters, num_threads);
 }

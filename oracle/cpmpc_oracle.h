@@ -159,7 +159,7 @@ int orc_opt_has_previous_solution(const orc_optimization* opt);
 
 /* One re-plan.  u_out[N]; predicted_out[N*4] (state-major per step), guess_out[dim] = the guess
  * actually handed to the solver, z_out[dim] = solver variables; any output may be NULL. */
-int orc_opt_step(orc_optimization* opt, const double state[4], const double dyn[9],
+int orc_opt_step(orc_optimization* opt, const double* state /*[nx]*/, const double* dyn /*[np]*/,
                  double set_point, double* u_out, double* predicted_out, double* guess_out,
                  double* z_out, orc_solver_summary* summary);
 
@@ -171,6 +171,32 @@ int orc_solve(const orc_opt_params* p, const orc_solver_opts* o, const double dy
 /* ---- Simulator (plant) --------------------------------------------------------------------- */
 void orc_sim_step(const double params[9], double dt, double u, const double f_base[2],
                   const double f_mass[2], double state[4]);
+
+/* ---- second model: cart + double pendulum (BASELINE config 5) ------------------------------ */
+/* Specified by symbolic/dynamics_double.py:25-148; the reference ships neither a generated header
+ * nor an optimizer for it (optimization.cc:197-199 hard-codes 4 states), so everything about this
+ * model is pinned by golden vectors from an independent SymPy/mpmath evaluation, finite differences
+ * and energy conservation only -- **parity unpinned** by the reference.
+ * State {b_x, th_1, th_2, b_x', th_1', th_2'}, params {m_b, m_1, m_2, l_1, l_2, g}.  The optimizer
+ * applies th_final / th_dot_final weights to both poles; targets are both poles upright. */
+enum { ORC_MODEL_SINGLE = 0, ORC_MODEL_DOUBLE = 1 };
+int orc_model_nx(int model);
+int orc_model_np(int model);
+void orc_dynamics_double(const double params[6], const double x[6], double u, const double f_base[2],
+                         const double f_mass[2], double f_out[6], double* Jx /*6x6*/, double* Ju /*6*/);
+double orc_energy_double(const double params[6], const double x[6]);
+void orc_rk4_model(int model, const double* params, const double* x, double u, double h, double* x_new,
+                   double* A /*nx*nx or NULL*/, double* B /*nx or NULL*/);
+void orc_shooting_constraint_model(int model, const double* params, int spacing, double dt,
+                                   const double* vars, double* err, double* J);
+void orc_problem_shape_model(int model, const orc_opt_params* p, int* dim, int* n_eq, int* n_cost);
+orc_optimization* orc_opt_create_model(const orc_opt_params* p, const orc_solver_opts* o, int model);
+int orc_opt_dim(const orc_optimization* opt);
+void orc_sim_step_model(int model, const double* params, double dt, double u, double* state);
+int orc_step_batch_cold_model(int model, const orc_opt_params* p, const orc_solver_opts* o,
+                              const double* dyn, double set_point, int64_t B, const double* x0_soa,
+                              double* u_out_soa, double* pred_out_soa, int32_t* status, int32_t* iters,
+                              int num_threads);
 
 /* ---- batch driver (cpu_baseline leg of bench.py; OpenMP over problems) --------------------- */
 /* SoA inputs like the product C-ABI: x0[4][B]; cold start for every problem.

@@ -147,6 +147,23 @@ def lib():
                                       C.c_int64, _dp, _dp, _dp, C.POINTER(C.c_int32),
                                       C.POINTER(C.c_int32), C.c_int]
     L.orc_step_batch_cold.restype = C.c_int
+    L.orc_model_nx.argtypes = [C.c_int]
+    L.orc_model_np.argtypes = [C.c_int]
+    L.orc_dynamics_double.argtypes = [_dp, _dp, C.c_double, _dp, _dp, _dp, _dp, _dp]
+    L.orc_energy_double.argtypes = [_dp, _dp]
+    L.orc_energy_double.restype = C.c_double
+    L.orc_rk4_model.argtypes = [C.c_int, _dp, _dp, C.c_double, C.c_double, _dp, _dp, _dp]
+    L.orc_shooting_constraint_model.argtypes = [C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, _dp]
+    L.orc_problem_shape_model.argtypes = [C.c_int, C.POINTER(OptParams), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                          C.POINTER(C.c_int)]
+    L.orc_opt_create_model.argtypes = [C.POINTER(OptParams), C.POINTER(SolverOpts), C.c_int]
+    L.orc_opt_create_model.restype = C.c_void_p
+    L.orc_opt_dim.argtypes = [C.c_void_p]
+    L.orc_sim_step_model.argtypes = [C.c_int, _dp, C.c_double, C.c_double, _dp]
+    L.orc_step_batch_cold_model.argtypes = [C.c_int, C.POINTER(OptParams), C.POINTER(SolverOpts), _dp, C.c_double,
+                                            C.c_int64, _dp, _dp, _dp, C.POINTER(C.c_int32),
+                                            C.POINTER(C.c_int32), C.c_int]
+    L.orc_step_batch_cold_model.restype = C.c_int
     _lib = L
     return L
 
@@ -270,6 +287,68 @@ def solve(p, dyn, x_current, set_point, u_prev, guess, opts=None):
     return z, s
 
 
+MODEL_SINGLE, MODEL_DOUBLE = 0, 1
+MODELS = {"single": MODEL_SINGLE, "double": MODEL_DOUBLE, 0: 0, 1: 1}
+
+
+def model_nx(model):
+    return lib().orc_model_nx(MODELS[model])
+
+
+def model_np(model):
+    return lib().orc_model_np(MODELS[model])
+
+
+def dynamics_double(params, x, u, jacobians=True):
+    params, x = _vec(params, 6), _vec(x, 6)
+    z2 = np.zeros(2)
+    f = np.zeros(6)
+    Jx = np.zeros((6, 6)) if jacobians else None
+    Ju = np.zeros(6) if jacobians else None
+    lib().orc_dynamics_double(_ptr(params), _ptr(x), float(u), _ptr(z2), _ptr(z2), _ptr(f), _ptr(Jx), _ptr(Ju))
+    return (f, Jx, Ju) if jacobians else f
+
+
+def energy_double(params, x):
+    params, x = _vec(params, 6), _vec(x, 6)
+    return lib().orc_energy_double(_ptr(params), _ptr(x))
+
+
+def rk4_model(model, params, x, u, h, jacobians=True):
+    m = MODELS[model]
+    nx = model_nx(m)
+    params, x = _vec(params, model_np(m)), _vec(x, nx)
+    xn = np.zeros(nx)
+    A = np.zeros((nx, nx)) if jacobians else None
+    B = np.zeros(nx) if jacobians else None
+    lib().orc_rk4_model(m, _ptr(params), _ptr(x), float(u), float(h), _ptr(xn), _ptr(A), _ptr(B))
+    return (xn, A, B) if jacobians else xn
+
+
+def shooting_constraint_model(model, params, spacing, dt, vars_, jacobian=True):
+    m = MODELS[model]
+    nx = model_nx(m)
+    params = _vec(params, model_np(m))
+    vars_ = _vec(vars_, 2 * nx + spacing)
+    err = np.zeros(nx)
+    J = np.zeros((nx, 2 * nx + spacing)) if jacobian else None
+    lib().orc_shooting_constraint_model(m, _ptr(params), int(spacing), float(dt), _ptr(vars_), _ptr(err), _ptr(J))
+    return (err, J) if jacobian else err
+
+
+def problem_shape_model(model, p):
+    d, e, c = C.c_int(), C.c_int(), C.c_int()
+    lib().orc_problem_shape_model(MODELS[model], C.byref(p), C.byref(d), C.byref(e), C.byref(c))
+    return d.value, e.value, c.value
+
+
+def sim_step_model(model, params, dt, u, state):
+    m = MODELS[model]
+    params, state = _vec(params, model_np(m)), _vec(state, model_nx(m)).copy()
+    lib().orc_sim_step_model(m, _ptr(params), float(dt), float(u), _ptr(state))
+    return state
+
+
 class StepOutputs:
     """Shape of pendulum::OptimizationOutputs (optimization.hpp:55-70)."""
 
@@ -286,10 +365,13 @@ class StepOutputs:
 class Optimization:
     """Oracle counterpart of pendulum::Optimization (optimization.hpp:73-108)."""
 
-    def __init__(self, params, opts=None):
+    def __init__(self, params, opts=None, model="single"):
         self.params = params
         self._opts = opts
-        self._h = lib().orc_opt_create(C.byref(params), C.byref(opts) if opts is not None else None)
+        self.model = MODELS[model]
+        self.nx = model_nx(self.model)
+        self._h = lib().orc_opt_create_model(C.byref(params), C.byref(opts) if opts is not None else None,
+                                             self.model)
         if not self._h:
             raise ValueError("invalid OptimizationParams (optimization.cc:13-22 preconditions)")
         self._prev = None
@@ -313,9 +395,9 @@ class Optimization:
 
     def step(self, state, dyn, set_point):
         p = self.params
-        N, dim = int(p.window_length), p.dim()
-        state, dyn = _vec(state, 4), _vec(dyn, 9)
-        u, pred = np.zeros(N), np.zeros((N, 4))
+        N, dim = int(p.window_length), lib().orc_opt_dim(self._h)
+        state, dyn = _vec(state, self.nx), _vec(dyn, model_np(self.model))
+        u, pred = np.zeros(N), np.zeros((N, self.nx))
         guess, z = np.zeros(dim), np.zeros(dim)
         s = SolverSummary()
         prev = self._prev.copy() if self._prev is not None else np.zeros(0)
@@ -347,18 +429,20 @@ class Simulator:
                            _ptr(self.state))
 
 
-def step_batch_cold(p, dyn, set_point, x0_soa, opts=None, want_pred=False, num_threads=0):
-    """x0_soa: [4, B].  Returns (u [N,B], pred [N,4,B] or None, status [B], iters [B], threads)."""
+def step_batch_cold(p, dyn, set_point, x0_soa, opts=None, want_pred=False, num_threads=0, model="single"):
+    """x0_soa: [nx, B].  Returns (u [N,B], pred [N,nx,B] or None, status [B], iters [B], threads)."""
+    m = MODELS[model]
+    nx = model_nx(m)
     x0 = np.ascontiguousarray(x0_soa, dtype=np.float64)
-    assert x0.ndim == 2 and x0.shape[0] == 4
+    assert x0.ndim == 2 and x0.shape[0] == nx
     B, N = x0.shape[1], int(p.window_length)
-    dyn = _vec(dyn, 9)
+    dyn = _vec(dyn, model_np(m))
     u = np.zeros((N, B))
-    pred = np.zeros((N, 4, B)) if want_pred else None
+    pred = np.zeros((N, nx, B)) if want_pred else None
     status = np.zeros(B, dtype=np.int32)
     iters = np.zeros(B, dtype=np.int32)
-    used = lib().orc_step_batch_cold(
-        C.byref(p), C.byref(opts) if opts is not None else None, _ptr(dyn), float(set_point), B,
+    used = lib().orc_step_batch_cold_model(
+        m, C.byref(p), C.byref(opts) if opts is not None else None, _ptr(dyn), float(set_point), B,
         _ptr(x0), _ptr(u), _ptr(pred), status.ctypes.data_as(C.POINTER(C.c_int32)),
         iters.ctypes.data_as(C.POINTER(C.c_int32)), int(num_threads))
     return u, pred, status, iters, used
