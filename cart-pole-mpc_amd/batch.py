@@ -66,8 +66,11 @@ class BatchOutputs:
 class BatchOptimization:
     """B independent pendulum::Optimization controllers solved in lock-step on one GPU."""
 
-    def __init__(self, params, max_batch, dtype=torch.float32, device=None, opts=None):
+    def __init__(self, params, max_batch, dtype=torch.float32, device=None, opts=None, model="single"):
         lib = capi.load()
+        self.model = capi.MODELS[model]
+        self.nx = lib.cpmpc_model_state_dim(self.model)
+        self.np = lib.cpmpc_model_num_params(self.model)
         if dtype not in _CAPI_DTYPE:
             raise TypeError("dtype must be torch.float32 or torch.float64")
         if device is None:
@@ -78,9 +81,9 @@ class BatchOptimization:
         self.device = int(device)
         self.max_batch = int(max_batch)
         self._h = C.c_void_p()
-        capi.check(lib.cpmpc_create(C.byref(params), C.byref(opts) if opts is not None else None,
-                                    _CAPI_DTYPE[dtype], self.max_batch, self.device,
-                                    C.byref(self._h)))
+        capi.check(lib.cpmpc_create_model(C.byref(params), C.byref(opts) if opts is not None else None,
+                                          _CAPI_DTYPE[dtype], self.max_batch, self.device, self.model,
+                                          C.byref(self._h)))
         self.N = int(params.window_length)
         self.S = lib.cpmpc_num_states(self._h)
         self.dim = lib.cpmpc_dim(self._h)
@@ -100,23 +103,23 @@ class BatchOptimization:
     # -- Optimization::Step -------------------------------------------------------------------
     def step(self, x0, dyn, set_point=0.0, want_predicted=True, want_stats=True, want_guess=False,
              out=None):
-        """x0: [4, B] tensor.  dyn: 9 floats (shared) or a [9, B] tensor.  set_point: float or [B]."""
+        """x0: [nx, B] tensor.  dyn: np floats (shared) or an [np, B] tensor.  set_point: float or [B]."""
         lib = capi.load()
         dev = torch.device("cuda", self.device)
         _require_cuda_tensor(x0, "x0", self.dtype)
-        if x0.dim() != 2 or x0.shape[0] != 4:
-            raise ValueError("x0 must be [4, B]")
+        if x0.dim() != 2 or x0.shape[0] != self.nx:
+            raise ValueError("x0 must be [%d, B]" % self.nx)
         B = int(x0.shape[1])
         inp = capi.StepInputs()
         inp.x0 = x0.data_ptr()
         keep = [x0]
         if isinstance(dyn, torch.Tensor):
-            _require_cuda_tensor(dyn, "dyn", self.dtype, (9, B))
+            _require_cuda_tensor(dyn, "dyn", self.dtype, (self.np, B))
             inp.dyn = dyn.data_ptr()
             inp.dyn_shared_host = None
             keep.append(dyn)
         else:
-            arr = capi.dbl_array(dyn, 9)
+            arr = capi.dbl_array(dyn, self.np)
             inp.dyn_shared_host = C.cast(arr, C.POINTER(C.c_double))
             inp.dyn = None
             keep.append(arr)
@@ -133,8 +136,8 @@ class BatchOptimization:
         if o.u is None or tuple(o.u.shape) != (self.N, B):
             o.u = torch.empty((self.N, B), dtype=self.dtype, device=dev)
         if want_predicted and (o.predicted_states is None
-                               or tuple(o.predicted_states.shape) != (self.N, 4, B)):
-            o.predicted_states = torch.empty((self.N, 4, B), dtype=self.dtype, device=dev)
+                               or tuple(o.predicted_states.shape) != (self.N, self.nx, B)):
+            o.predicted_states = torch.empty((self.N, self.nx, B), dtype=self.dtype, device=dev)
         if o.status is None or o.status.numel() != B:
             o.status = torch.empty((B,), dtype=torch.int32, device=dev)
         if want_stats and (o.iterations is None or o.iterations.numel() != B):
@@ -187,10 +190,11 @@ class BatchOptimization:
         _require_cuda_tensor(z, "z", self.dtype)
         B = int(z.shape[1])
         dev = z.device
-        c = torch.empty((4 * (self.S - 1), B), dtype=self.dtype, device=dev)
-        Phi = torch.empty((self.S - 1, 4, 4, B), dtype=self.dtype, device=dev)
-        Gam = torch.empty((self.N, 4, B), dtype=self.dtype, device=dev)
-        arr = capi.dbl_array(dyn, 9)
+        nx = self.nx
+        c = torch.empty((nx * (self.S - 1), B), dtype=self.dtype, device=dev)
+        Phi = torch.empty((self.S - 1, nx, nx, B), dtype=self.dtype, device=dev)
+        Gam = torch.empty((self.N, nx, B), dtype=self.dtype, device=dev)
+        arr = capi.dbl_array(dyn, self.np)
         with torch.cuda.device(self.device):
             capi.check(capi.load().cpmpc_linearize_batch(self._h, B, arr, _ptr(z), _ptr(c), _ptr(Phi),
                                                          _ptr(Gam), _stream_ptr()))
@@ -218,49 +222,63 @@ def _fext(fext):
     return None if fext is None else capi.dbl_array(fext, 4)
 
 
-def dynamics_batch(dyn, x, u, fext=None, jacobians=True):
-    """gen::single_pendulum_dynamics batched: x [4,B], u [B] -> f [4,B] (+ Jx [4,4,B], Ju [4,B])."""
+def _model_dims(model):
+    lib = capi.load()
+    m = capi.MODELS[model]
+    return m, lib.cpmpc_model_state_dim(m), lib.cpmpc_model_num_params(m)
+
+
+def dynamics_batch(dyn, x, u, fext=None, jacobians=True, model="single"):
+    """Forward dynamics batched (gen::single_pendulum_dynamics or the generated double pendulum):
+    x [nx,B], u [B] -> f [nx,B] (+ Jx [nx,nx,B], Ju [nx,B])."""
+    m, nx, npar = _model_dims(model)
     dt = x.dtype
     _require_cuda_tensor(x, "x", dt)
     B = int(x.shape[1])
+    if x.shape[0] != nx:
+        raise ValueError("x must be [%d, B]" % nx)
     _require_cuda_tensor(u, "u", dt, (B,))
     f = torch.empty_like(x)
-    Jx = torch.empty((4, 4, B), dtype=dt, device=x.device) if jacobians else None
-    Ju = torch.empty((4, B), dtype=dt, device=x.device) if jacobians else None
+    Jx = torch.empty((nx, nx, B), dtype=dt, device=x.device) if jacobians else None
+    Ju = torch.empty((nx, B), dtype=dt, device=x.device) if jacobians else None
     with torch.cuda.device(x.device):
-        capi.check(capi.load().cpmpc_dynamics_batch(_CAPI_DTYPE[dt], B, capi.dbl_array(dyn, 9), _ptr(x),
-                                                    _ptr(u), _fext(fext), _ptr(f), _ptr(Jx), _ptr(Ju),
-                                                    _stream_ptr()))
+        capi.check(capi.load().cpmpc_dynamics_batch_model(m, _CAPI_DTYPE[dt], B, capi.dbl_array(dyn, npar), _ptr(x),
+                                                          _ptr(u), _fext(fext), _ptr(f), _ptr(Jx), _ptr(Ju),
+                                                          _stream_ptr()))
     return (f, Jx, Ju) if jacobians else f
 
 
-def rk4_batch(dyn, x, u, h, fext=None, jacobians=True):
-    """runge_kutta_4th_order<4> (or _no_jacobians) batched: -> x_new [4,B] (+ A [4,4,B], B [4,B])."""
+def rk4_batch(dyn, x, u, h, fext=None, jacobians=True, model="single"):
+    """runge_kutta_4th_order<D> (or _no_jacobians) batched: -> x_new [nx,B] (+ A [nx,nx,B], B [nx,B])."""
+    m, nx, npar = _model_dims(model)
     dt = x.dtype
     _require_cuda_tensor(x, "x", dt)
     B = int(x.shape[1])
+    if x.shape[0] != nx:
+        raise ValueError("x must be [%d, B]" % nx)
     _require_cuda_tensor(u, "u", dt, (B,))
     xn = torch.empty_like(x)
-    A = torch.empty((4, 4, B), dtype=dt, device=x.device) if jacobians else None
-    Bm = torch.empty((4, B), dtype=dt, device=x.device) if jacobians else None
+    A = torch.empty((nx, nx, B), dtype=dt, device=x.device) if jacobians else None
+    Bm = torch.empty((nx, B), dtype=dt, device=x.device) if jacobians else None
     with torch.cuda.device(x.device):
-        capi.check(capi.load().cpmpc_rk4_batch(_CAPI_DTYPE[dt], B, capi.dbl_array(dyn, 9), _ptr(x), _ptr(u),
-                                               float(h), _fext(fext), _ptr(xn), _ptr(A), _ptr(Bm),
-                                               _stream_ptr()))
+        capi.check(capi.load().cpmpc_rk4_batch_model(m, _CAPI_DTYPE[dt], B, capi.dbl_array(dyn, npar), _ptr(x),
+                                                     _ptr(u), float(h), _fext(fext), _ptr(xn), _ptr(A), _ptr(Bm),
+                                                     _stream_ptr()))
     return (xn, A, Bm) if jacobians else xn
 
 
 class BatchSimulator:
     """B independent pendulum::Simulator plants (optimization/simulator.hpp:10-29)."""
 
-    def __init__(self, batch, dtype=torch.float32, device=None):
-        capi.load()
+    def __init__(self, batch, dtype=torch.float32, device=None, model="single"):
+        self.model, self.nx, self.np = _model_dims(model)
         if device is None:
             device = torch.cuda.current_device()
         self.device = torch.device("cuda", int(device))
         self.dtype = dtype
-        init = torch.tensor([0.0, -3.14159265358979323846 / 2, 0.0, 0.0], dtype=dtype)  # simulator.hpp:28
-        self.state = init.to(self.device).reshape(4, 1).repeat(1, int(batch)).contiguous()
+        hang = -3.14159265358979323846 / 2  # poles hanging, at rest (simulator.hpp:28)
+        init = torch.tensor([0.0] + [hang] * (self.nx // 2 - 1) + [0.0] * (self.nx // 2), dtype=dtype)
+        self.state = init.to(self.device).reshape(self.nx, 1).repeat(1, int(batch)).contiguous()
 
     def get_state(self):
         return self.state
@@ -278,6 +296,6 @@ class BatchSimulator:
         if fext is not None:
             _require_cuda_tensor(fext, "fext", self.dtype, (4, B))
         with torch.cuda.device(self.device):
-            capi.check(capi.load().cpmpc_sim_step_batch(_CAPI_DTYPE[self.dtype], B, capi.dbl_array(params, 9),
-                                                        float(dt), _ptr(u), shared, _ptr(fext),
-                                                        _ptr(self.state), _stream_ptr()))
+            capi.check(capi.load().cpmpc_sim_step_batch_model(self.model, _CAPI_DTYPE[self.dtype], B,
+                                                              capi.dbl_array(params, self.np), float(dt), _ptr(u),
+                                                              shared, _ptr(fext), _ptr(self.state), _stream_ptr()))

@@ -12,6 +12,8 @@ LIB_PATH = os.environ.get("CPMPC_LIB") or os.path.join(_HERE, "lib", "libcpmpc.s
 
 OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC, ERR_BATCH = range(7)
 F32, F64 = 0, 1
+MODEL_SINGLE, MODEL_DOUBLE = 0, 1
+MODELS = {"single": MODEL_SINGLE, "double": MODEL_DOUBLE, 0: 0, 1: 1}
 
 TERM_NAMES = {
     0: "NONE", 1: "MAX_ITERATIONS", 2: "SATISFIED_ABSOLUTE_TOL", 3: "SATISFIED_RELATIVE_TOL",
@@ -30,7 +32,9 @@ SYMBOLS = [
     "cpmpc_has_previous_solution", "cpmpc_dim", "cpmpc_num_states", "cpmpc_dtype",
     "cpmpc_step_batch_host", "cpmpc_set_previous_solution_host", "cpmpc_get_solution_host",
     "cpmpc_dynamics_batch", "cpmpc_rk4_batch", "cpmpc_linearize_batch", "cpmpc_sim_step_batch",
-    "cpmpc_sim_step_batch_host", "cpmpc_profile_enable", "cpmpc_profile_reset", "cpmpc_profile_read", "cpmpc_kernel_name",
+    "cpmpc_sim_step_batch_host", "cpmpc_model_state_dim", "cpmpc_model_num_params", "cpmpc_create_model",
+    "cpmpc_model", "cpmpc_dynamics_batch_model", "cpmpc_rk4_batch_model", "cpmpc_sim_step_batch_model",
+    "cpmpc_profile_enable", "cpmpc_profile_reset", "cpmpc_profile_read", "cpmpc_kernel_name",
 ]
 
 
@@ -145,6 +149,13 @@ def load():
     L.cpmpc_linearize_batch.argtypes = [vp, i64, _dp, vp, vp, vp, vp, vp]
     L.cpmpc_sim_step_batch.argtypes = [i32, i64, _dp, dbl, vp, _dp, vp, vp, vp]
     L.cpmpc_sim_step_batch_host.argtypes = [i64, _dp, dbl, _dp, _dp, _dp]
+    L.cpmpc_model_state_dim.argtypes = [i32]
+    L.cpmpc_model_num_params.argtypes = [i32]
+    L.cpmpc_create_model.argtypes = [C.POINTER(Params), C.POINTER(SolverOpts), i32, i64, i32, i32, C.POINTER(vp)]
+    L.cpmpc_model.argtypes = [vp]
+    L.cpmpc_dynamics_batch_model.argtypes = [i32, i32, i64, _dp, vp, vp, _dp, vp, vp, vp, vp]
+    L.cpmpc_rk4_batch_model.argtypes = [i32, i32, i64, _dp, vp, vp, dbl, _dp, vp, vp, vp, vp]
+    L.cpmpc_sim_step_batch_model.argtypes = [i32, i32, i64, _dp, dbl, vp, _dp, vp, vp, vp]
     L.cpmpc_profile_enable.argtypes = [vp, i32]
     L.cpmpc_profile_reset.argtypes = [vp]
     L.cpmpc_profile_read.argtypes = [vp, i32, _dp, C.POINTER(C.c_int64)]

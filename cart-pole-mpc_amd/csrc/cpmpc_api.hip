@@ -121,6 +121,40 @@ struct DeviceGuard {
 };
 
 // ------------------------------------------------------------------------------------------------
+// models
+// ------------------------------------------------------------------------------------------------
+static int model_nx(int model) { return model == CPMPC_MODEL_DOUBLE ? 6 : 4; }
+static int model_np(int model) { return model == CPMPC_MODEL_DOUBLE ? 6 : 9; }
+extern "C" int cpmpc_model_state_dim(int model) {
+  return (model == CPMPC_MODEL_SINGLE || model == CPMPC_MODEL_DOUBLE) ? model_nx(model) : -1;
+}
+extern "C" int cpmpc_model_num_params(int model) {
+  return (model == CPMPC_MODEL_SINGLE || model == CPMPC_MODEL_DOUBLE) ? model_np(model) : -1;
+}
+
+// run `body` with R and M bound to the (dtype, model) pair
+#define CPMPC_DISPATCH(dtype, model, body)                \
+  do {                                                    \
+    if ((dtype) == CPMPC_F32 && (model) == CPMPC_MODEL_SINGLE) { \
+      using R = float;                                    \
+      using M = SingleModel<float>;                       \
+      body;                                               \
+    } else if ((dtype) == CPMPC_F64 && (model) == CPMPC_MODEL_SINGLE) { \
+      using R = double;                                   \
+      using M = SingleModel<double>;                      \
+      body;                                               \
+    } else if ((dtype) == CPMPC_F32) {                    \
+      using R = float;                                    \
+      using M = DoubleModel<float>;                       \
+      body;                                               \
+    } else {                                              \
+      using R = double;                                   \
+      using M = DoubleModel<double>;                      \
+      body;                                               \
+    }                                                     \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------
 // the handle
 // ------------------------------------------------------------------------------------------------
 struct ProfSpan {
@@ -132,9 +166,10 @@ struct cpmpc_solver {
   cpmpc_params params;
   cpmpc_solver_opts opts;
   int dtype;
+  int model;
   int device;
   int64_t cap;  // workspace stride (capacity rounded up to a multiple of 64)
-  int N, S, SP, dim;
+  int N, S, SP, NX, NP, dim;
   size_t esize;
   // one allocation, carved into fields
   void* ws = nullptr;
@@ -179,12 +214,13 @@ static int validate_params(const cpmpc_params* p) {
   return CPMPC_OK;
 }
 
-extern "C" int cpmpc_create(const cpmpc_params* params, const cpmpc_solver_opts* opts, int dtype,
-                            int64_t max_batch, int device, cpmpc_solver** out) {
+extern "C" int cpmpc_create_model(const cpmpc_params* params, const cpmpc_solver_opts* opts, int dtype,
+                                  int64_t max_batch, int device, int model, cpmpc_solver** out) {
   if (!params || !out) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
   *out = nullptr;
   if (dtype != CPMPC_F32 && dtype != CPMPC_F64) return fail(CPMPC_ERR_INVALID_ARG, "dtype must be CPMPC_F32 or CPMPC_F64");
-  if (max_batch < 1) return fail(CPMPC_ERR_INVALID_ARG, "max_batch must be >= 1");
+  if (model != CPMPC_MODEL_SINGLE && model != CPMPC_MODEL_DOUBLE) return fail(CPMPC_ERR_INVALID_ARG, "unknown model");
+  if (max_batch < 1 || max_batch > (1ll << 30)) return fail(CPMPC_ERR_INVALID_ARG, "max_batch must be in [1, 2^30]");
   int rc = validate_params(params);
   if (rc) return rc;
   rc = check_device(device);
@@ -199,16 +235,21 @@ extern "C" int cpmpc_create(const cpmpc_params* params, const cpmpc_solver_opts*
   else
     cpmpc_default_solver_opts(&s->opts);
   s->dtype = dtype;
+  s->model = model;
   s->device = device;
   s->esize = dtype == CPMPC_F32 ? 4 : 8;
+  s->NX = model_nx(model);
+  s->NP = model_np(model);
   s->N = (int)params->window_length;
   s->SP = (int)params->state_spacing;
   s->S = s->N / s->SP + 1;  // optimization.hpp:52
-  s->dim = 4 * s->S + s->N;
+  s->dim = s->NX * s->S + s->N;  // optimization.cc:204-205
   s->cap = (max_batch + 63) / 64 * 64;
 
-  // scalars of the dtype per problem: 4-vector fields count 4 (nodes, dz nodes, Phi rows, Gamma, defects, W, T)
-  const size_t fields_real = (size_t)4 * (2 * s->S + 4 * (s->S - 1) + s->N + (s->S - 1) + 2 * s->N) + 2 * s->N + SC_COUNT;
+  // scalars of the dtype per problem; an NX-vector field occupies XW = 4 or 8 scalars
+  const size_t XW = s->NX > 4 ? 8 : 4;
+  const size_t n_xv = (size_t)2 * s->S + (size_t)s->NX * (s->S - 1) + s->N + (s->S - 1) + s->N;  // zx dzx Phi Gam cs Wk
+  const size_t fields_real = XW * n_xv + 4 * (size_t)s->N + 2 * (size_t)s->N + SC_COUNT;
   const size_t bytes_real = fields_real * (size_t)s->cap * s->esize;
   const size_t bytes_int = (size_t)IS_COUNT * (size_t)s->cap * sizeof(int32_t);
   s->ws_bytes = bytes_real + bytes_int;
@@ -225,13 +266,13 @@ extern "C" int cpmpc_create(const cpmpc_params* params, const cpmpc_solver_opts*
     pch += nfields * (size_t)s->cap * s->esize;
     return r;
   };
-  // 4-vector fields first so that every one of them is 16/32-byte aligned (cap is a multiple of 64)
-  s->zx = carve(4 * s->S);
-  s->dzx = carve(4 * s->S);
-  s->Phi = carve(16 * (s->S - 1));
-  s->Gam = carve(4 * s->N);
-  s->cs = carve(4 * (s->S - 1));
-  s->Wk = carve(4 * s->N);
+  // vector fields first so that every one of them is 16/32-byte aligned (cap is a multiple of 64)
+  s->zx = carve(XW * s->S);
+  s->dzx = carve(XW * s->S);
+  s->Phi = carve(XW * s->NX * (s->S - 1));
+  s->Gam = carve(XW * s->N);
+  s->cs = carve(XW * (s->S - 1));
+  s->Wk = carve(XW * s->N);
   s->Tk = carve(4 * s->N);
   s->zu = carve(s->N);
   s->dzu = carve(s->N);
@@ -265,6 +306,11 @@ extern "C" int cpmpc_create(const cpmpc_params* params, const cpmpc_solver_opts*
   return CPMPC_OK;
 }
 
+extern "C" int cpmpc_create(const cpmpc_params* params, const cpmpc_solver_opts* opts, int dtype,
+                            int64_t max_batch, int device, cpmpc_solver** out) {
+  return cpmpc_create_model(params, opts, dtype, max_batch, device, CPMPC_MODEL_SINGLE, out);
+}
+
 extern "C" void cpmpc_destroy(cpmpc_solver* s) {
   if (!s) return;
   DeviceGuard guard(s->device);
@@ -285,6 +331,7 @@ extern "C" void cpmpc_destroy(cpmpc_solver* s) {
 extern "C" int cpmpc_dim(const cpmpc_solver* s) { return s ? s->dim : -1; }
 extern "C" int cpmpc_num_states(const cpmpc_solver* s) { return s ? s->S : -1; }
 extern "C" int cpmpc_dtype(const cpmpc_solver* s) { return s ? s->dtype : -1; }
+extern "C" int cpmpc_model(const cpmpc_solver* s) { return s ? s->model : -1; }
 extern "C" int cpmpc_has_previous_solution(const cpmpc_solver* s) { return s ? s->has_prev : 0; }
 
 extern "C" int cpmpc_reset(cpmpc_solver* s) {  // Optimization::Reset, optimization.hpp:83
@@ -361,11 +408,11 @@ extern "C" int cpmpc_profile_read(cpmpc_solver* s, int kernel, double* total_ms,
 // ------------------------------------------------------------------------------------------------
 static inline dim3 grid_for(int64_t threads) { return dim3((unsigned)((threads + 63) / 64)); }
 
-template <typename R>
-static void fill_args(const cpmpc_solver* s, int64_t B, SolverArgs<R>& a) {
+template <typename R, typename M>
+static void fill_args(const cpmpc_solver* s, int64_t B, SolverArgs<R, M>& a) {
   const cpmpc_params& p = s->params;
   const cpmpc_solver_opts& o = s->opts;
-  memset(&a, 0, sizeof a);
+  memset((void*)&a, 0, sizeof a);
   a.B = B;
   a.stride = s->cap;
   a.N = s->N;
@@ -375,14 +422,27 @@ static void fill_args(const cpmpc_solver* s, int64_t B, SolverArgs<R>& a) {
   // rows exist only for strictly positive weights (optimization.cc:270,296)
   a.wu = (R)(p.u_cost_weight > 0.0 ? p.u_cost_weight : 0.0);
   a.wd = (R)(p.u_derivative_cost_weight > 0.0 ? p.u_derivative_cost_weight : 0.0);
-  const double w[4] = {p.b_x_final_cost_weight, p.th_final_cost_weight, p.b_x_dot_final_cost_weight,
-                       p.th_dot_final_cost_weight};
-  const double tgt[4] = {0.0, M_PI / 2, 0.0, 0.0};  // optimization.cc:236-267
+  // terminal rows in BuildProblem order (optimization.cc:236-267).  For the double pendulum (no optimizer
+  // in the reference) th_final / th_dot_final apply to both poles, both targets are upright.
   a.term_is_cost = 0;
-  for (int t = 0; t < 4; ++t) {
-    const bool is_cost = w[t] >= 0.0;
-    a.term_w[t] = (R)(is_cost ? w[t] : 1.0);
-    a.term_tgt[t] = (R)tgt[t];
+  for (int t = 0; t < M::NX; ++t) {
+    double w, tgt;
+    if (t == 0) {
+      w = p.b_x_final_cost_weight;
+      tgt = 0.0;
+    } else if (t < M::NQ) {
+      w = p.th_final_cost_weight;
+      tgt = M_PI / 2;
+    } else if (t == M::NQ) {
+      w = p.b_x_dot_final_cost_weight;
+      tgt = 0.0;
+    } else {
+      w = p.th_dot_final_cost_weight;
+      tgt = 0.0;
+    }
+    const bool is_cost = w >= 0.0;
+    a.term_w[t] = (R)(is_cost ? w : 1.0);
+    a.term_tgt[t] = (R)tgt;
     if (is_cost) a.term_is_cost |= (1 << t);
   }
   a.max_ls = o.max_line_search_iterations;
@@ -404,27 +464,28 @@ static void fill_args(const cpmpc_solver* s, int64_t B, SolverArgs<R>& a) {
   a.mu_init = (R)p.equality_penalty_initial;
   a.has_prev = s->has_prev;
   using V4 = typename VecT<R>::V4;
-  a.zx = (V4*)s->zx;
+  using XVn = XV<R, M::NX>;
+  a.zx = (XVn*)s->zx;
   a.zu = (R*)s->zu;
-  a.dzx = (V4*)s->dzx;
+  a.dzx = (XVn*)s->dzx;
   a.dzu = (R*)s->dzu;
-  a.Phi = (V4*)s->Phi;
-  a.Gam = (V4*)s->Gam;
-  a.cs = (V4*)s->cs;
-  a.Wk = (V4*)s->Wk;
+  a.Phi = (XVn*)s->Phi;
+  a.Gam = (XVn*)s->Gam;
+  a.cs = (XVn*)s->cs;
+  a.Wk = (XVn*)s->Wk;
   a.Tk = (V4*)s->Tk;
   a.sc = (R*)s->sc;
   a.ist = s->ist;
   a.sin_table = (const R*)s->sin_table;
 }
 
-template <typename R>
-static void launch_linearize(const SolverArgs<R>& a, int SP, const typename VecT<R>::V4* zx_in, const R* zu_in,
+template <typename R, typename M>
+static void launch_linearize(const SolverArgs<R, M>& a, int SP, const XV<R, M::NX>* zx_in, const R* zu_in,
                              const int32_t* status, hipStream_t stream) {
   const dim3 grid = grid_for(a.B * (a.S - 1));
 #define CPMPC_LIN(SPV)                                                                                       \
   case SPV:                                                                                                  \
-    hipLaunchKernelGGL((linearize_kernel<R, SPV>), grid, dim3(64), 0, stream, a, zx_in, zu_in, status);      \
+    hipLaunchKernelGGL((linearize_kernel<R, M, SPV>), grid, dim3(64), 0, stream, a, zx_in, zu_in, status);   \
     break;
   switch (SP) {
     CPMPC_LIN(1)
@@ -440,17 +501,15 @@ static void launch_linearize(const SolverArgs<R>& a, int SP, const typename VecT
 #undef CPMPC_LIN
 }
 
-template <typename R>
+template <typename R, typename M>
 static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* in, const cpmpc_step_outputs* out,
                            hipStream_t stream) {
-  SolverArgs<R> a;
-  fill_args<R>(s, B, a);
+  SolverArgs<R, M> a;
+  fill_args<R, M>(s, B, a);
   a.x0 = (const R*)in->x0;
   a.dyn = (const R*)in->dyn;
   a.set_point = (const R*)in->set_point;
-  if (in->dyn == nullptr) {
-    a.consts = make_consts<R, double>(in->dyn_shared_host);
-  }
+  if (in->dyn == nullptr) a.consts = M::template make<double>(in->dyn_shared_host);
   a.term_tgt[0] = (R)in->set_point_shared;
   if (out) {
     a.u_out = (R*)out->u;
@@ -466,20 +525,20 @@ static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* 
   ProfSpan sp;
 
   span_begin(s, CPMPC_KERNEL_PREPARE, stream, &sp);
-  hipLaunchKernelGGL((prepare_kernel<R>), gridB, dim3(64), 0, stream, a);
+  hipLaunchKernelGGL((prepare_kernel<R, M>), gridB, dim3(64), 0, stream, a);
   span_end(s, stream, &sp);
 
   for (int it = 0; it < (int)s->params.max_iterations; ++it) {
     span_begin(s, CPMPC_KERNEL_LINEARIZE, stream, &sp);
-    launch_linearize<R>(a, s->SP, a.zx, a.zu, a.ist, stream);
+    launch_linearize<R, M>(a, s->SP, a.zx, a.zu, a.ist, stream);
     span_end(s, stream, &sp);
     span_begin(s, CPMPC_KERNEL_QP_LS, stream, &sp);
-    hipLaunchKernelGGL((qp_ls_kernel<R>), gridB, dim3(64), 0, stream, a);
+    hipLaunchKernelGGL((qp_ls_kernel<R, M>), gridB, dim3(64), 0, stream, a);
     span_end(s, stream, &sp);
   }
 
   span_begin(s, CPMPC_KERNEL_FINALIZE, stream, &sp);
-  hipLaunchKernelGGL((finalize_kernel<R>), gridB, dim3(64), 0, stream, a);
+  hipLaunchKernelGGL((finalize_kernel<R, M>), gridB, dim3(64), 0, stream, a);
   span_end(s, stream, &sp);
 
   HIP_TRY(hipGetLastError());
@@ -498,8 +557,9 @@ extern "C" int cpmpc_step_batch(cpmpc_solver* s, int64_t B, const cpmpc_step_inp
   if (!in->set_point && !std::isfinite(in->set_point_shared))
     return fail(CPMPC_ERR_INVALID_ARG, "set_point_shared must be finite");
   DeviceGuard guard(s->device);
-  if (s->dtype == CPMPC_F32) return step_batch_impl<float>(s, B, in, out, (hipStream_t)stream);
-  return step_batch_impl<double>(s, B, in, out, (hipStream_t)stream);
+  int rc = CPMPC_OK;
+  CPMPC_DISPATCH(s->dtype, s->model, (rc = step_batch_impl<R, M>(s, B, in, out, (hipStream_t)stream)));
+  return rc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -510,12 +570,9 @@ extern "C" int cpmpc_set_previous_solution(cpmpc_solver* s, int64_t B, const voi
   if (B < 1 || B > s->cap) return fail(CPMPC_ERR_BATCH, "B out of range");
   DeviceGuard guard(s->device);
   // packed [dim][B] (MapKey order) -> workspace layout
-  if (s->dtype == CPMPC_F32)
-    hipLaunchKernelGGL((pack_z_kernel<float>), grid_for(B), dim3(64), 0, (hipStream_t)stream, B, s->cap, s->S, s->N,
-                       (const float*)z, (float4*)s->zx, (float*)s->zu);
-  else
-    hipLaunchKernelGGL((pack_z_kernel<double>), grid_for(B), dim3(64), 0, (hipStream_t)stream, B, s->cap, s->S, s->N,
-                       (const double*)z, (double4*)s->zx, (double*)s->zu);
+  CPMPC_DISPATCH(s->dtype, s->model,
+                 hipLaunchKernelGGL((pack_z_kernel<R, M::NX>), grid_for(B), dim3(64), 0, (hipStream_t)stream, B,
+                                    s->cap, s->S, s->N, (const R*)z, (XV<R, M::NX>*)s->zx, (R*)s->zu));
   HIP_TRY(hipGetLastError());
   s->has_prev = 1;
   return CPMPC_OK;
@@ -525,12 +582,9 @@ extern "C" int cpmpc_get_solution(cpmpc_solver* s, int64_t B, void* z_out, void*
   if (!s || !z_out) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
   if (B < 1 || B > s->cap) return fail(CPMPC_ERR_BATCH, "B out of range");
   DeviceGuard guard(s->device);
-  if (s->dtype == CPMPC_F32)
-    hipLaunchKernelGGL((unpack_z_kernel<float>), grid_for(B), dim3(64), 0, (hipStream_t)stream, B, s->cap, s->S,
-                       s->N, (const float4*)s->zx, (const float*)s->zu, (float*)z_out);
-  else
-    hipLaunchKernelGGL((unpack_z_kernel<double>), grid_for(B), dim3(64), 0, (hipStream_t)stream, B, s->cap, s->S,
-                       s->N, (const double4*)s->zx, (const double*)s->zu, (double*)z_out);
+  CPMPC_DISPATCH(s->dtype, s->model,
+                 hipLaunchKernelGGL((unpack_z_kernel<R, M::NX>), grid_for(B), dim3(64), 0, (hipStream_t)stream, B,
+                                    s->cap, s->S, s->N, (const XV<R, M::NX>*)s->zx, (const R*)s->zu, (R*)z_out));
   HIP_TRY(hipGetLastError());
   return CPMPC_OK;
 }
@@ -555,12 +609,12 @@ static void to_dev_type(const double* src, size_t n, std::vector<R>& dst) {
   for (size_t i = 0; i < n; ++i) dst[i] = (R)src[i];
 }
 
-template <typename R>
+template <typename R, typename M>
 static int step_host_impl(cpmpc_solver* s, int64_t B, const double* x0_host, const double* dyn_shared_host,
                           double set_point, double* u_host, double* predicted_host, int32_t* status_host,
                           int32_t* iterations_host, double* final_cost_host, double* final_eq_l1_host) {
   const size_t nB = (size_t)B;
-  const size_t n_x0 = 4 * nB, n_u = (size_t)s->N * nB, n_pred = 4 * (size_t)s->N * nB;
+  const size_t n_x0 = (size_t)M::NX * nB, n_u = (size_t)s->N * nB, n_pred = (size_t)M::NX * (size_t)s->N * nB;
   const size_t bytes = (n_x0 + n_u + n_pred + 2 * nB) * sizeof(R) + 2 * nB * sizeof(int32_t);
   int rc = ensure_stage(s, bytes);
   if (rc) return rc;
@@ -589,7 +643,7 @@ static int step_host_impl(cpmpc_solver* s, int64_t B, const double* x0_host, con
   out.iterations = d_iters;
   out.final_cost = d_cost;
   out.final_eq_l1 = d_eq;
-  rc = step_batch_impl<R>(s, B, &in, &out, nullptr);
+  rc = step_batch_impl<R, M>(s, B, &in, &out, nullptr);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(nullptr));
 
@@ -618,11 +672,11 @@ extern "C" int cpmpc_step_batch_host(cpmpc_solver* s, int64_t B, const double* x
   if (B > s->cap) return fail(CPMPC_ERR_BATCH, "B exceeds capacity");
   if (!std::isfinite(set_point)) return fail(CPMPC_ERR_INVALID_ARG, "set_point must be finite");
   DeviceGuard guard(s->device);
-  if (s->dtype == CPMPC_F32)
-    return step_host_impl<float>(s, B, x0_host, dyn_shared_host, set_point, u_host, predicted_host, status_host,
-                                 iterations_host, final_cost_host, final_eq_l1_host);
-  return step_host_impl<double>(s, B, x0_host, dyn_shared_host, set_point, u_host, predicted_host, status_host,
-                                iterations_host, final_cost_host, final_eq_l1_host);
+  int rc = CPMPC_OK;
+  CPMPC_DISPATCH(s->dtype, s->model,
+                 (rc = step_host_impl<R, M>(s, B, x0_host, dyn_shared_host, set_point, u_host, predicted_host,
+                                            status_host, iterations_host, final_cost_host, final_eq_l1_host)));
+  return rc;
 }
 
 extern "C" int cpmpc_set_previous_solution_host(cpmpc_solver* s, int64_t B, const double* z_host) {
@@ -686,87 +740,83 @@ static ExtForce<R> ext_from_host(const double* fext_host) {
   return fe;
 }
 
-extern "C" int cpmpc_dynamics_batch(int dtype, int64_t B, const double* dyn_shared_host, const void* x,
-                                    const void* u, const double* fext_host, void* f, void* Jx, void* Ju,
-                                    void* stream) {
-  if (!dyn_shared_host || !x || !u || !f) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
+static int check_piece_args(int model, int dtype, int64_t B) {
+  if (model != CPMPC_MODEL_SINGLE && model != CPMPC_MODEL_DOUBLE) return fail(CPMPC_ERR_INVALID_ARG, "unknown model");
+  if (dtype != CPMPC_F32 && dtype != CPMPC_F64) return fail(CPMPC_ERR_INVALID_ARG, "bad dtype");
   if (B < 1) return fail(CPMPC_ERR_INVALID_ARG, "B must be >= 1");
-  int rc = current_device_ok();
+  return current_device_ok();
+}
+
+extern "C" int cpmpc_dynamics_batch_model(int model, int dtype, int64_t B, const double* dyn_shared_host,
+                                          const void* x, const void* u, const double* fext_host, void* f, void* Jx,
+                                          void* Ju, void* stream) {
+  if (!dyn_shared_host || !x || !u || !f) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
+  int rc = check_piece_args(model, dtype, B);
   if (rc) return rc;
-  if (dtype == CPMPC_F32) {
-    hipLaunchKernelGGL((dynamics_kernel<float>), grid_for(B), dim3(64), 0, (hipStream_t)stream, B,
-                       make_consts<float, double>(dyn_shared_host), ext_from_host<float>(fext_host),
-                       (const float*)x, (const float*)u, (float*)f, (float*)Jx, (float*)Ju);
-  } else if (dtype == CPMPC_F64) {
-    hipLaunchKernelGGL((dynamics_kernel<double>), grid_for(B), dim3(64), 0, (hipStream_t)stream, B,
-                       make_consts<double, double>(dyn_shared_host), ext_from_host<double>(fext_host),
-                       (const double*)x, (const double*)u, (double*)f, (double*)Jx, (double*)Ju);
-  } else {
-    return fail(CPMPC_ERR_INVALID_ARG, "bad dtype");
-  }
+  CPMPC_DISPATCH(dtype, model,
+                 hipLaunchKernelGGL((dynamics_kernel<R, M>), grid_for(B), dim3(64), 0, (hipStream_t)stream, B,
+                                    M::template make<double>(dyn_shared_host), ext_from_host<R>(fext_host),
+                                    (const R*)x, (const R*)u, (R*)f, (R*)Jx, (R*)Ju));
   HIP_TRY(hipGetLastError());
   return CPMPC_OK;
 }
+extern "C" int cpmpc_dynamics_batch(int dtype, int64_t B, const double* dyn_shared_host, const void* x,
+                                    const void* u, const double* fext_host, void* f, void* Jx, void* Ju,
+                                    void* stream) {
+  return cpmpc_dynamics_batch_model(CPMPC_MODEL_SINGLE, dtype, B, dyn_shared_host, x, u, fext_host, f, Jx, Ju, stream);
+}
 
-extern "C" int cpmpc_rk4_batch(int dtype, int64_t B, const double* dyn_shared_host, const void* x, const void* u,
-                               double h, const double* fext_host, void* x_new, void* A, void* Bm, void* stream) {
+extern "C" int cpmpc_rk4_batch_model(int model, int dtype, int64_t B, const double* dyn_shared_host, const void* x,
+                                     const void* u, double h, const double* fext_host, void* x_new, void* A,
+                                     void* Bm, void* stream) {
   if (!dyn_shared_host || !x || !u || !x_new) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
-  if (B < 1) return fail(CPMPC_ERR_INVALID_ARG, "B must be >= 1");
-  int rc = current_device_ok();
+  int rc = check_piece_args(model, dtype, B);
   if (rc) return rc;
-  if (dtype == CPMPC_F32) {
-    hipLaunchKernelGGL((rk4_kernel<float>), grid_for(B), dim3(64), 0, (hipStream_t)stream, B,
-                       make_consts<float, double>(dyn_shared_host), ext_from_host<float>(fext_host), (float)h,
-                       (const float*)x, (const float*)u, (float*)x_new, (float*)A, (float*)Bm);
-  } else if (dtype == CPMPC_F64) {
-    hipLaunchKernelGGL((rk4_kernel<double>), grid_for(B), dim3(64), 0, (hipStream_t)stream, B,
-                       make_consts<double, double>(dyn_shared_host), ext_from_host<double>(fext_host), h,
-                       (const double*)x, (const double*)u, (double*)x_new, (double*)A, (double*)Bm);
-  } else {
-    return fail(CPMPC_ERR_INVALID_ARG, "bad dtype");
-  }
+  CPMPC_DISPATCH(dtype, model,
+                 hipLaunchKernelGGL((rk4_kernel<R, M>), grid_for(B), dim3(64), 0, (hipStream_t)stream, B,
+                                    M::template make<double>(dyn_shared_host), ext_from_host<R>(fext_host), (R)h,
+                                    (const R*)x, (const R*)u, (R*)x_new, (R*)A, (R*)Bm));
   HIP_TRY(hipGetLastError());
   return CPMPC_OK;
+}
+extern "C" int cpmpc_rk4_batch(int dtype, int64_t B, const double* dyn_shared_host, const void* x, const void* u,
+                               double h, const double* fext_host, void* x_new, void* A, void* Bm, void* stream) {
+  return cpmpc_rk4_batch_model(CPMPC_MODEL_SINGLE, dtype, B, dyn_shared_host, x, u, h, fext_host, x_new, A, Bm,
+                               stream);
+}
+
+template <typename R, typename M>
+static void linearize_batch_impl(cpmpc_solver* s, int64_t B, const double* dyn_shared_host, const void* z, void* c,
+                                 void* Phi, void* Gamma, hipStream_t st) {
+  SolverArgs<R, M> a;
+  fill_args<R, M>(s, B, a);
+  a.consts = M::template make<double>(dyn_shared_host);
+  hipLaunchKernelGGL((pack_z_kernel<R, M::NX>), grid_for(B), dim3(64), 0, st, B, s->cap, s->S, s->N, (const R*)z,
+                     a.dzx, a.dzu);
+  launch_linearize<R, M>(a, s->SP, a.dzx, a.dzu, nullptr, st);
+  hipLaunchKernelGGL((unpack_lin_kernel<R, M>), grid_for(B), dim3(64), 0, st, a, (R*)c, (R*)Phi, (R*)Gamma);
 }
 
 extern "C" int cpmpc_linearize_batch(cpmpc_solver* s, int64_t B, const double* dyn_shared_host, const void* z,
                                      void* c, void* Phi, void* Gamma, void* stream) {
   if (!s || !dyn_shared_host || !z || !c || !Phi || !Gamma) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
   if (B < 1) return fail(CPMPC_ERR_INVALID_ARG, "B must be >= 1");
-  DeviceGuard guard(s->device);
   if (B > s->cap) return fail(CPMPC_ERR_BATCH, "B exceeds capacity");
+  DeviceGuard guard(s->device);
   // the caller's z is packed into the step buffers (dzx/dzu), which hold no state between calls, so the
   // warm start (zx/zu) is untouched; the linearisation lands in the workspace and is unpacked
-  hipStream_t st = (hipStream_t)stream;
-  if (s->dtype == CPMPC_F32) {
-    SolverArgs<float> a;
-    fill_args<float>(s, B, a);
-    a.consts = make_consts<float, double>(dyn_shared_host);
-    hipLaunchKernelGGL((pack_z_kernel<float>), grid_for(B), dim3(64), 0, st, B, s->cap, s->S, s->N, (const float*)z,
-                       a.dzx, a.dzu);
-    launch_linearize<float>(a, s->SP, a.dzx, a.dzu, nullptr, st);
-    hipLaunchKernelGGL((unpack_lin_kernel<float>), grid_for(B), dim3(64), 0, st, a, (float*)c, (float*)Phi,
-                       (float*)Gamma);
-  } else {
-    SolverArgs<double> a;
-    fill_args<double>(s, B, a);
-    a.consts = make_consts<double, double>(dyn_shared_host);
-    hipLaunchKernelGGL((pack_z_kernel<double>), grid_for(B), dim3(64), 0, st, B, s->cap, s->S, s->N, (const double*)z,
-                       a.dzx, a.dzu);
-    launch_linearize<double>(a, s->SP, a.dzx, a.dzu, nullptr, st);
-    hipLaunchKernelGGL((unpack_lin_kernel<double>), grid_for(B), dim3(64), 0, st, a, (double*)c, (double*)Phi,
-                       (double*)Gamma);
-  }
+  CPMPC_DISPATCH(s->dtype, s->model,
+                 (linearize_batch_impl<R, M>(s, B, dyn_shared_host, z, c, Phi, Gamma, (hipStream_t)stream)));
   HIP_TRY(hipGetLastError());
   return CPMPC_OK;
 }
 
-extern "C" int cpmpc_sim_step_batch(int dtype, int64_t B, const double* dyn_shared_host, double dt, const void* u,
-                                    const double* fext_host, const void* fext, void* state, void* stream) {
+extern "C" int cpmpc_sim_step_batch_model(int model, int dtype, int64_t B, const double* dyn_shared_host, double dt,
+                                          const void* u, const double* fext_host, const void* fext, void* state,
+                                          void* stream) {
   if (!dyn_shared_host || !u || !state) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
-  if (B < 1) return fail(CPMPC_ERR_INVALID_ARG, "B must be >= 1");
   if (!(dt >= 0.0) || !std::isfinite(dt)) return fail(CPMPC_ERR_INVALID_ARG, "dt must be finite and >= 0 (simulator.cc:13)");
-  int rc = current_device_ok();
+  int rc = check_piece_args(model, dtype, B);
   if (rc) return rc;
   // simulator.cc:18-22 evaluated in double: number of sub-steps and the size of the last one
   const double internal_dt = 0.001;
@@ -782,19 +832,17 @@ extern "C" int cpmpc_sim_step_batch(int dtype, int64_t B, const double* dyn_shar
     }
   }
   if (n_sub == 0) return CPMPC_OK;
-  if (dtype == CPMPC_F32) {
-    hipLaunchKernelGGL((sim_kernel<float>), grid_for(B), dim3(64), 0, (hipStream_t)stream, B,
-                       make_consts<float, double>(dyn_shared_host), ext_from_host<float>(fext_host),
-                       (const float*)fext, n_sub, (float)h_last, (const float*)u, (float*)state);
-  } else if (dtype == CPMPC_F64) {
-    hipLaunchKernelGGL((sim_kernel<double>), grid_for(B), dim3(64), 0, (hipStream_t)stream, B,
-                       make_consts<double, double>(dyn_shared_host), ext_from_host<double>(fext_host),
-                       (const double*)fext, n_sub, h_last, (const double*)u, (double*)state);
-  } else {
-    return fail(CPMPC_ERR_INVALID_ARG, "bad dtype");
-  }
+  CPMPC_DISPATCH(dtype, model,
+                 hipLaunchKernelGGL((sim_kernel<R, M>), grid_for(B), dim3(64), 0, (hipStream_t)stream, B,
+                                    M::template make<double>(dyn_shared_host), ext_from_host<R>(fext_host),
+                                    (const R*)fext, n_sub, (R)h_last, (const R*)u, (R*)state));
   HIP_TRY(hipGetLastError());
   return CPMPC_OK;
+}
+extern "C" int cpmpc_sim_step_batch(int dtype, int64_t B, const double* dyn_shared_host, double dt, const void* u,
+                                    const double* fext_host, const void* fext, void* state, void* stream) {
+  return cpmpc_sim_step_batch_model(CPMPC_MODEL_SINGLE, dtype, B, dyn_shared_host, dt, u, fext_host, fext, state,
+                                    stream);
 }
 
 extern "C" int cpmpc_sim_step_batch_host(int64_t B, const double* dyn_shared_host, double dt, const double* u_host,

@@ -1,0 +1,280 @@
+// models.hpp -- model policies (cart + single pole, cart + double pole) and the model-generic RK4
+// steps with and without sensitivities.  A model is a second-order mechanical system
+//     x = [q (NQ positions: base, then pole angles); q' (NQ velocities)],   x' = [q'; a(x, u)]
+// and provides the accelerations a with their partials Ja = da/dx (NQ x NX) and Jua = da/du (NQ).
+// The full stage Jacobian is [[0 I],[Ja]]; only Ja is ever materialised.
+//
+// Reference: runge_kutta_4th_order<D> / _no_jacobians (optimization/integration.hpp:13-62), which is
+// templated on the state dimension D exactly for this generalisation (optimization.cc:197-199).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "cartpole_device.hpp"
+#include "double_pendulum_gen.hpp"
+
+namespace cpmpc {
+
+// ------------------------------------------------------------------------------------------------
+// cart + single pole: gen::single_pendulum_dynamics (single_pendulum_dynamics.hpp:13-186)
+// ------------------------------------------------------------------------------------------------
+template <typename R>
+struct SingleModel {
+  static constexpr int NX = 4, NQ = 2, NP = 9;
+  using Consts = CartPoleConsts<R>;
+  template <typename P>
+  __host__ __device__ static Consts make(const P* p) {
+    return make_consts<R, P>(p);
+  }
+  template <bool WITH_J, bool HAS_EXT>
+  __device__ __forceinline__ static void accel(const Consts& k, const R (&x)[NX], const R u,
+                                               const ExtForce<R>& fe, R (&a)[NQ], R (&Ja)[NQ][NX],
+                                               R (&Jua)[NQ]) {
+    cartpole_accel<R, WITH_J, HAS_EXT>(k, x[0], x[1], x[2], x[3], u, fe, a[0], a[1], Ja, Jua);
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// cart + double pole: symbolic/dynamics_double.py:25-148 (generated terms, numeric 3x3 solve)
+//   a = M^-1 F,  da/dx_c = M^-1 (dF/dx_c - dM/dx_c a),  da/du = M^-1 e_0.  No dissipation, no
+//   external forces (HAS_EXT is ignored).
+// ------------------------------------------------------------------------------------------------
+template <typename R>
+struct DoubleConsts {
+  R p[6];  // m_b, m_1, m_2, l_1, l_2, g
+};
+
+template <typename R>
+struct DoubleModel {
+  static constexpr int NX = 6, NQ = 3, NP = 6;
+  using Consts = DoubleConsts<R>;
+  template <typename P>
+  __host__ __device__ static Consts make(const P* p) {
+    Consts k;
+    for (int i = 0; i < 6; ++i) k.p[i] = R(p[i]);
+    return k;
+  }
+  // LDL^T of the symmetric positive definite 3x3 mass matrix
+  __device__ __forceinline__ static void factor(const R* M, R (&L)[3], R (&id)[3]) {
+    const R d0 = M[0];
+    id[0] = Math<R>::rcp(d0);
+    L[0] = M[3] * id[0];
+    L[1] = M[6] * id[0];
+    const R d1 = M[4] - L[0] * L[0] * d0;
+    id[1] = Math<R>::rcp(d1);
+    L[2] = (M[7] - L[1] * L[0] * d0) * id[1];
+    const R d2 = M[8] - L[1] * L[1] * d0 - L[2] * L[2] * d1;
+    id[2] = Math<R>::rcp(d2);
+  }
+  __device__ __forceinline__ static void solve(const R (&L)[3], const R (&id)[3], const R b0, const R b1,
+                                               const R b2, R (&y)[3]) {
+    const R z0 = b0;
+    const R z1 = b1 - L[0] * z0;
+    const R z2 = b2 - L[1] * z0 - L[2] * z1;
+    y[2] = z2 * id[2];
+    y[1] = z1 * id[1] - L[2] * y[2];
+    y[0] = z0 * id[0] - L[0] * y[1] - L[1] * y[2];
+  }
+  template <bool WITH_J, bool HAS_EXT>
+  __device__ __forceinline__ static void accel(const Consts& k, const R (&x)[NX], const R u,
+                                               const ExtForce<R>&, R (&a)[NQ], R (&Ja)[NQ][NX],
+                                               R (&Jua)[NQ]) {
+    R M[9], F[3], dFdx[18], dM1[9], dM2[9], L[3], id[3];
+    double_pendulum_terms<R>(k.p, x, u, M, F, dFdx, dM1, dM2);
+    factor(M, L, id);
+    solve(L, id, F[0], F[1], F[2], a);
+    if (WITH_J) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        R r0 = dFdx[0 * 6 + c], r1 = dFdx[1 * 6 + c], r2 = dFdx[2 * 6 + c];
+        if (c == 1 || c == 2) {
+          const R* dM = (c == 1) ? dM1 : dM2;
+          r0 -= dM[0] * a[0] + dM[1] * a[1] + dM[2] * a[2];
+          r1 -= dM[3] * a[0] + dM[4] * a[1] + dM[5] * a[2];
+          r2 -= dM[6] * a[0] + dM[7] * a[1] + dM[8] * a[2];
+        }
+        R y[3];
+        solve(L, id, r0, r1, r2, y);
+        Ja[0][c] = y[0];
+        Ja[1][c] = y[1];
+        Ja[2][c] = y[2];
+      }
+      solve(L, id, R(1), R(0), R(0), Jua);
+    }
+  }
+};
+
+// pole angles are components 1..NQ-1 (wrapped to (-pi, pi]); component 0 is the base position (clamped)
+template <typename M>
+__host__ __device__ constexpr bool is_angle(int t) {
+  return t >= 1 && t < M::NQ;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RK4 without sensitivities (integration.hpp:52-62).  x updated in place.
+// ------------------------------------------------------------------------------------------------
+template <typename R, typename M, bool HAS_EXT>
+__device__ __forceinline__ void rk4_step_m(const typename M::Consts& k, const R h, R (&x)[M::NX], const R u,
+                                           const ExtForce<R>& fe) {
+  constexpr int NX = M::NX, NQ = M::NQ;
+  R Ja[NQ][NX], Jua[NQ];
+  R a1[NQ], a2[NQ], a3[NQ], a4[NQ], v2[NQ], v3[NQ], v4[NQ], xt[NX];
+  const R hh = h / R(2);
+  M::template accel<false, HAS_EXT>(k, x, u, fe, a1, Ja, Jua);  // k1 = [x_v; a1]
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    v2[i] = x[NQ + i] + a1[i] * hh;
+    xt[i] = x[i] + x[NQ + i] * hh;
+    xt[NQ + i] = v2[i];
+  }
+  M::template accel<false, HAS_EXT>(k, xt, u, fe, a2, Ja, Jua);  // k2 = [v2; a2]
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    v3[i] = x[NQ + i] + a2[i] * hh;
+    xt[i] = x[i] + v2[i] * hh;
+    xt[NQ + i] = v3[i];
+  }
+  M::template accel<false, HAS_EXT>(k, xt, u, fe, a3, Ja, Jua);  // k3 = [v3; a3]
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    v4[i] = x[NQ + i] + a3[i] * h;
+    xt[i] = x[i] + v3[i] * h;
+    xt[NQ + i] = v4[i];
+  }
+  M::template accel<false, HAS_EXT>(k, xt, u, fe, a4, Ja, Jua);  // k4 = [v4; a4]
+  const R h6 = h / R(6);
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const R v1 = x[NQ + i];
+    x[i] += h6 * (v1 + v2[i] * R(2) + v3[i] * R(2) + v4[i]);
+    x[NQ + i] += h6 * (a1[i] + a2[i] * R(2) + a3[i] * R(2) + a4[i]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// RK4 with sensitivities A = dx+/dx (NX x NX), Bv = dx+/du (NX)   (integration.hpp:13-49).
+//   D_1 = K_1,  D_{j+1} = K_{j+1} (I + a_j D_j),  a = {h/2, h/2, h},  A = I + h/6 (D_1 + 2 D_2 + 2 D_3 + D_4)
+// With K = [[0 I],[Ja]] the top NQ rows of K X are the bottom NQ rows of X and the bottom NQ rows are
+// Ja X, so each stage product costs NQ*NX*NX multiply-adds instead of NX^3.
+// ------------------------------------------------------------------------------------------------
+template <typename R, int NX, int NQ>
+__device__ __forceinline__ void stage_chain_m(const R (&Ja)[NQ][NX], const R (&Jua)[NQ], const R a,
+                                              const R (&D)[NX][NX], const R (&d)[NX], R (&Dn)[NX][NX],
+                                              R (&dn)[NX]) {
+#pragma unroll
+  for (int c = 0; c < NX; ++c) {
+#pragma unroll
+    for (int r = 0; r < NQ; ++r) Dn[r][c] = a * D[NQ + r][c] + (c == NQ + r ? R(1) : R(0));
+#pragma unroll
+    for (int r = 0; r < NQ; ++r) {
+      R acc = Ja[r][0] * D[0][c];
+#pragma unroll
+      for (int kk = 1; kk < NX; ++kk) acc += Ja[r][kk] * D[kk][c];
+      Dn[NQ + r][c] = Ja[r][c] + a * acc;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < NQ; ++r) {
+    dn[r] = a * d[NQ + r];
+    R acc = Ja[r][0] * d[0];
+#pragma unroll
+    for (int kk = 1; kk < NX; ++kk) acc += Ja[r][kk] * d[kk];
+    dn[NQ + r] = a * acc + Jua[r];
+  }
+}
+
+template <typename R, typename M, bool HAS_EXT>
+__device__ __forceinline__ void rk4_step_jac_m(const typename M::Consts& k, const R h, R (&x)[M::NX],
+                                               const R u, const ExtForce<R>& fe, R (&A)[M::NX][M::NX],
+                                               R (&Bv)[M::NX]) {
+  constexpr int NX = M::NX, NQ = M::NQ;
+  const R hh = h / R(2);
+  R Ja[NQ][NX], Jua[NQ];
+  R D[NX][NX], d[NX], Dn[NX][NX], dn[NX];
+  R As[NX][NX], bs[NX];  // running sums D_1 + 2 D_2 + 2 D_3 + D_4
+  R a1[NQ], a2[NQ], a3[NQ], a4[NQ], v2[NQ], v3[NQ], v4[NQ], xt[NX];
+
+  // stage 1
+  M::template accel<true, HAS_EXT>(k, x, u, fe, a1, Ja, Jua);
+#pragma unroll
+  for (int r = 0; r < NQ; ++r) {
+#pragma unroll
+    for (int c = 0; c < NX; ++c) {
+      D[r][c] = (c == NQ + r ? R(1) : R(0));
+      D[NQ + r][c] = Ja[r][c];
+    }
+    d[r] = R(0);
+    d[NQ + r] = Jua[r];
+  }
+#pragma unroll
+  for (int r = 0; r < NX; ++r) {
+#pragma unroll
+    for (int c = 0; c < NX; ++c) As[r][c] = D[r][c];
+    bs[r] = d[r];
+  }
+
+  // stage 2
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    v2[i] = x[NQ + i] + a1[i] * hh;
+    xt[i] = x[i] + x[NQ + i] * hh;
+    xt[NQ + i] = v2[i];
+  }
+  M::template accel<true, HAS_EXT>(k, xt, u, fe, a2, Ja, Jua);
+  stage_chain_m<R, NX, NQ>(Ja, Jua, hh, D, d, Dn, dn);
+#pragma unroll
+  for (int r = 0; r < NX; ++r) {
+#pragma unroll
+    for (int c = 0; c < NX; ++c) {
+      As[r][c] += Dn[r][c] * R(2);
+      D[r][c] = Dn[r][c];
+    }
+    bs[r] += dn[r] * R(2);
+    d[r] = dn[r];
+  }
+
+  // stage 3
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    v3[i] = x[NQ + i] + a2[i] * hh;
+    xt[i] = x[i] + v2[i] * hh;
+    xt[NQ + i] = v3[i];
+  }
+  M::template accel<true, HAS_EXT>(k, xt, u, fe, a3, Ja, Jua);
+  stage_chain_m<R, NX, NQ>(Ja, Jua, hh, D, d, Dn, dn);
+#pragma unroll
+  for (int r = 0; r < NX; ++r) {
+#pragma unroll
+    for (int c = 0; c < NX; ++c) {
+      As[r][c] += Dn[r][c] * R(2);
+      D[r][c] = Dn[r][c];
+    }
+    bs[r] += dn[r] * R(2);
+    d[r] = dn[r];
+  }
+
+  // stage 4
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    v4[i] = x[NQ + i] + a3[i] * h;
+    xt[i] = x[i] + v3[i] * h;
+    xt[NQ + i] = v4[i];
+  }
+  M::template accel<true, HAS_EXT>(k, xt, u, fe, a4, Ja, Jua);
+  stage_chain_m<R, NX, NQ>(Ja, Jua, h, D, d, Dn, dn);
+
+  const R h6 = h / R(6);
+#pragma unroll
+  for (int r = 0; r < NX; ++r) {
+#pragma unroll
+    for (int c = 0; c < NX; ++c) A[r][c] = (r == c ? R(1) : R(0)) + h6 * (As[r][c] + Dn[r][c]);
+    Bv[r] = h6 * (bs[r] + dn[r]);
+  }
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const R v1 = x[NQ + i];
+    x[i] += h6 * (v1 + v2[i] * R(2) + v3[i] * R(2) + v4[i]);
+    x[NQ + i] += h6 * (a1[i] + a2[i] * R(2) + a3[i] * R(2) + a4[i]);
+  }
+}
+
+}  // namespace cpmpc

@@ -198,6 +198,31 @@ int cpmpc_sim_step_batch(int dtype, int64_t B, const double* dyn_shared_host, do
                          const void* u, const double* fext_host, const void* fext, void* state,
                          void* stream);
 
+/* ---- models ----------------------------------------------------------------------------------- */
+/* CPMPC_MODEL_SINGLE: the reference's cart + single pole (4 states, 9 parameters), everything above.
+ * CPMPC_MODEL_DOUBLE: cart + double pole of symbolic/dynamics_double.py:25-148 (BASELINE config 5):
+ *   state {b_x, th_1, th_2, b_x', th_1', th_2'} (6), parameters {m_b, m_1, m_2, l_1, l_2, g} (6), no
+ *   dissipation / external forces.  The reference has no optimizer for it (optimization.cc:197-199
+ *   hard-codes 4 states); here the same OptimizationParams apply with th_final / th_dot_final acting on
+ *   both poles and both poles' targets upright, variables laid out by MapKey<6>.
+ * With a model argument every array's leading extent 4 becomes the model's state dimension and the
+ * parameter vector its parameter count. */
+enum { CPMPC_MODEL_SINGLE = 0, CPMPC_MODEL_DOUBLE = 1 };
+int cpmpc_model_state_dim(int model);  /* 4 or 6; -1 for an unknown model */
+int cpmpc_model_num_params(int model); /* 9 or 6 */
+int cpmpc_create_model(const cpmpc_params* params, const cpmpc_solver_opts* opts /*nullable*/, int dtype,
+                       int64_t max_batch, int device, int model, cpmpc_solver** out);
+int cpmpc_model(const cpmpc_solver* s);
+int cpmpc_dynamics_batch_model(int model, int dtype, int64_t B, const double* dyn_shared_host, const void* x,
+                               const void* u, const double* fext_host, void* f, void* Jx, void* Ju,
+                               void* stream);
+int cpmpc_rk4_batch_model(int model, int dtype, int64_t B, const double* dyn_shared_host, const void* x,
+                          const void* u, double h, const double* fext_host, void* x_new, void* A, void* Bm,
+                          void* stream);
+int cpmpc_sim_step_batch_model(int model, int dtype, int64_t B, const double* dyn_shared_host, double dt,
+                               const void* u, const double* fext_host, const void* fext, void* state,
+                               void* stream);
+
 /* Host-pointer convenience for Simulator::Step (fp64 on the GPU; used by the C++ facade):
  * state_host [4][B] in/out, u_host [B], fext_host shared or NULL.  No CPU compute path. */
 int cpmpc_sim_step_batch_host(int64_t B, const double* dyn_shared_host, double dt,

@@ -150,7 +150,7 @@ def main():
     c_code = emit(model, "double", banner)
     with open(os.path.join(ROOT, "oracle", "double_pendulum_gen.inc"), "w") as fh:
         fh.write(c_code)
-    hip = emit(model, "R", banner + ["#pragma once"])
+    hip = emit(model, "R", banner + ["#pragma once", "namespace cpmpc {"]) + "}  // namespace cpmpc\n"
     with open(os.path.join(ROOT, "cart-pole-mpc_amd", "csrc", "double_pendulum_gen.hpp"), "w") as fh:
         fh.write(hip)
     print("M =", model["M"])
