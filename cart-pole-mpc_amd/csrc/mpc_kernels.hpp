@@ -40,6 +40,24 @@ enum { IS_STATUS = 0, IS_ITERS, IS_LS_EVALS, IS_FAILED, IS_COUNT };
 
 constexpr int kMaxNX = 6;
 
+// occupancy hints (second argument of __launch_bounds__ = minimum waves per SIMD); 0 = compiler's choice
+#ifndef CPMPC_QPLS_WAVES
+#define CPMPC_QPLS_WAVES 0
+#endif
+#ifndef CPMPC_LIN_WAVES
+#define CPMPC_LIN_WAVES 0
+#endif
+#if CPMPC_QPLS_WAVES > 0
+#define CPMPC_QPLS_BOUNDS __launch_bounds__(64, CPMPC_QPLS_WAVES)
+#else
+#define CPMPC_QPLS_BOUNDS __launch_bounds__(64)
+#endif
+#if CPMPC_LIN_WAVES > 0
+#define CPMPC_LIN_BOUNDS __launch_bounds__(64, CPMPC_LIN_WAVES)
+#else
+#define CPMPC_LIN_BOUNDS __launch_bounds__(64)
+#endif
+
 template <typename R>
 struct VecT;
 template <>
@@ -223,7 +241,7 @@ __global__ __launch_bounds__(64) void prepare_kernel(const SolverArgs<R, M> a) {
 // equal to the reference's backward accumulation (optimization.cc:145-154).
 // ------------------------------------------------------------------------------------------------
 template <typename R, typename M, int SP>
-__global__ __launch_bounds__(64) void linearize_kernel(const SolverArgs<R, M> a, const XV<R, M::NX>* zx_in,
+__global__ CPMPC_LIN_BOUNDS void linearize_kernel(const SolverArgs<R, M> a, const XV<R, M::NX>* zx_in,
                                                         const R* zu_in, const int32_t* status) {
   constexpr int NX = M::NX;
   const int64_t gid = (int64_t)blockIdx.x * 64 + threadIdx.x;
@@ -409,7 +427,7 @@ __device__ __forceinline__ void merit_eval(const SolverArgs<R, M>& a, const type
 // backtracking, started from the remembered step length.
 // ------------------------------------------------------------------------------------------------
 template <typename R, typename M>
-__global__ __launch_bounds__(64) void qp_ls_kernel(const SolverArgs<R, M> a) {
+__global__ CPMPC_QPLS_BOUNDS void qp_ls_kernel(const SolverArgs<R, M> a) {
   using V4 = typename VecT<R>::V4;
   using XVn = XV<R, M::NX>;
   constexpr int NX = M::NX;
