@@ -37,6 +37,8 @@ FLOPS_PER_LAUNCH_UNIT = {
     "qp_ls_kernel": FLOPS_QP + FLOPS_MERIT,   # nominal: one merit evaluation per iteration
     "prepare_kernel": FLOPS_MERIT,
     "finalize_kernel": FLOPS_MERIT,
+    # one launch = all SQP iterations; multiplied by --iters below
+    "fused_sqp_kernel": FLOPS_LINEARIZE + FLOPS_QP + FLOPS_MERIT,
 }
 PEAK_VALU_TFLOPS = {"f32": 157.3, "f64": 78.6}  # MI355X_MICROARCH.md (vector peak); f64 = public spec
 PEAK_HBM_GBPS = 8000.0
@@ -77,6 +79,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--pipeline", choices=["auto", "split", "fused"], default="auto")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -103,6 +106,7 @@ def main():
     x0_np = synth_states(1000 + rank, B)  # rank-specific shard of the global synthetic batch
     x0 = torch.tensor(x0_np, dtype=tdt, device=dev)
     opt = pkg.BatchOptimization(params, max_batch=B, dtype=tdt, device=local_rank)
+    opt.set_pipeline(args.pipeline)
     outs = [pkg.BatchOutputs(), pkg.BatchOutputs()]
     gather = None
     if world > 1 and not args.no_gather:
@@ -151,7 +155,7 @@ def main():
     dom = max(prof, key=lambda k: prof[k][0])
     dom_ms, dom_n = prof[dom]
     avg_s = dom_ms / max(dom_n, 1) * 1e-3
-    flops_launch = FLOPS_PER_LAUNCH_UNIT[dom] * B
+    flops_launch = FLOPS_PER_LAUNCH_UNIT[dom] * B * (args.iters if dom == "fused_sqp_kernel" else 1)
     achieved_tf = flops_launch / avg_s / 1e12
     peak_tf = PEAK_VALU_TFLOPS[args.dtype]
     esz = 4 if args.dtype == "f32" else 8
@@ -161,7 +165,7 @@ def main():
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if tj.get("dtype") == args.dtype and tj.get("batch") == B:
+            if tj.get("dtype") == args.dtype and tj.get("batch") == B and dom in tj.get("per_launch_bytes", {}):
                 traffic = tj.get("per_launch_bytes", {}).get(dom)
         except Exception:
             traffic = None
@@ -191,7 +195,7 @@ def main():
         "config": {"workload": "BASELINE configs[2]: batch=%d per GPU, N=40, state_spacing=10, %s, cold start, "
                                "%d SQP iterations (exits disabled), u+predicted+status written%s"
                                % (B, args.dtype, args.iters, ", u gathered to rank 0 (RCCL)" if gather else ""),
-                   "batch_per_gpu": B, "horizon": N, "sqp_iterations": args.iters,
+                   "batch_per_gpu": B, "horizon": N, "sqp_iterations": args.iters, "pipeline": opt.pipeline(),
                    "parallelism": "dp%d" % world},
         "roofline": roofline,
     }

@@ -200,6 +200,14 @@ class BatchOptimization:
                                                          _ptr(Gam), _stream_ptr()))
         return c, Phi, Gam
 
+    # -- pipeline selection --------------------------------------------------------------------
+    def set_pipeline(self, mode):
+        """'auto' | 'split' | 'fused' (include/cpmpc.h: CPMPC_PIPELINE_*)."""
+        capi.check(capi.load().cpmpc_set_pipeline(self._h, capi.PIPELINES[mode]))
+
+    def pipeline(self):
+        return {capi.PIPELINE_SPLIT: "split", capi.PIPELINE_FUSED: "fused"}[capi.load().cpmpc_get_pipeline(self._h)]
+
     # -- measurement --------------------------------------------------------------------------
     def profile_enable(self, on=True):
         capi.check(capi.load().cpmpc_profile_enable(self._h, 1 if on else 0))

@@ -22,7 +22,9 @@ TERM_NAMES = {
 }
 TERM = {v: k for k, v in TERM_NAMES.items()}
 
-KERNEL_PREPARE, KERNEL_LINEARIZE, KERNEL_QP_LS, KERNEL_FINALIZE, KERNEL_COUNT = range(5)
+KERNEL_PREPARE, KERNEL_LINEARIZE, KERNEL_QP_LS, KERNEL_FINALIZE, KERNEL_FUSED, KERNEL_COUNT = range(6)
+PIPELINE_AUTO, PIPELINE_SPLIT, PIPELINE_FUSED = 0, 1, 2
+PIPELINES = {"auto": 0, "split": 1, "fused": 2, 0: 0, 1: 1, 2: 2}
 
 # every symbol include/cpmpc.h declares (tests check the library exports all of them)
 SYMBOLS = [
@@ -34,6 +36,7 @@ SYMBOLS = [
     "cpmpc_dynamics_batch", "cpmpc_rk4_batch", "cpmpc_linearize_batch", "cpmpc_sim_step_batch",
     "cpmpc_sim_step_batch_host", "cpmpc_model_state_dim", "cpmpc_model_num_params", "cpmpc_create_model",
     "cpmpc_model", "cpmpc_dynamics_batch_model", "cpmpc_rk4_batch_model", "cpmpc_sim_step_batch_model",
+    "cpmpc_set_pipeline", "cpmpc_get_pipeline",
     "cpmpc_profile_enable", "cpmpc_profile_reset", "cpmpc_profile_read", "cpmpc_kernel_name",
 ]
 
@@ -156,6 +159,8 @@ def load():
     L.cpmpc_dynamics_batch_model.argtypes = [i32, i32, i64, _dp, vp, vp, _dp, vp, vp, vp, vp]
     L.cpmpc_rk4_batch_model.argtypes = [i32, i32, i64, _dp, vp, vp, dbl, _dp, vp, vp, vp, vp]
     L.cpmpc_sim_step_batch_model.argtypes = [i32, i32, i64, _dp, dbl, vp, _dp, vp, vp, vp]
+    L.cpmpc_set_pipeline.argtypes = [vp, i32]
+    L.cpmpc_get_pipeline.argtypes = [vp]
     L.cpmpc_profile_enable.argtypes = [vp, i32]
     L.cpmpc_profile_reset.argtypes = [vp]
     L.cpmpc_profile_read.argtypes = [vp, i32, _dp, C.POINTER(C.c_int64)]

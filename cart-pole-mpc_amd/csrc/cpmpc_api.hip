@@ -15,6 +15,7 @@
 
 #include "../../include/cpmpc.h"
 #include "mpc_kernels.hpp"
+#include "mpc_fused.hpp"
 
 using namespace cpmpc;
 
@@ -185,8 +186,9 @@ struct cpmpc_solver {
   int profiling = 0;
   std::vector<ProfSpan> spans;
   std::vector<ProfSpan> free_spans;
-  double prof_ms[CPMPC_KERNEL_COUNT] = {0, 0, 0, 0};
-  int64_t prof_n[CPMPC_KERNEL_COUNT] = {0, 0, 0, 0};
+  double prof_ms[CPMPC_KERNEL_COUNT] = {0, 0, 0, 0, 0};
+  int64_t prof_n[CPMPC_KERNEL_COUNT] = {0, 0, 0, 0, 0};
+  int pipeline = CPMPC_PIPELINE_AUTO;
 };
 
 extern "C" int cpmpc_supported_state_spacing(int spacing) {
@@ -344,7 +346,7 @@ extern "C" int cpmpc_reset(cpmpc_solver* s) {  // Optimization::Reset, optimizat
 // profiling spans
 // ------------------------------------------------------------------------------------------------
 static const char* kKernelNames[CPMPC_KERNEL_COUNT] = {"prepare_kernel", "linearize_kernel", "qp_ls_kernel",
-                                                       "finalize_kernel"};
+                                                       "finalize_kernel", "fused_sqp_kernel"};
 extern "C" const char* cpmpc_kernel_name(int kernel) {
   return (kernel >= 0 && kernel < CPMPC_KERNEL_COUNT) ? kKernelNames[kernel] : "?";
 }
@@ -501,6 +503,49 @@ static void launch_linearize(const SolverArgs<R, M>& a, int SP, const XV<R, M::N
 #undef CPMPC_LIN
 }
 
+// fused pipeline: built for the single pendulum and these (L = S-1, SP) pairs
+static bool fused_built(int model, int L, int SP) {
+  if (model != CPMPC_MODEL_SINGLE) return false;
+  return (L == 4 && SP == 10) || (L == 8 && SP == 5) || (L == 2 && SP == 10) || (L == 4 && SP == 5);
+}
+static bool use_fused(const cpmpc_solver* s) {
+  if (s->pipeline == CPMPC_PIPELINE_SPLIT) return false;
+  return fused_built(s->model, s->S - 1, s->SP);
+}
+
+template <typename R, typename M>
+static void launch_fused(const SolverArgs<R, M>& a, int L, int SP, int max_iters, hipStream_t stream) {
+  if constexpr (M::NX == 4) {
+    const int ppw = 64 / L;
+    const dim3 grid((unsigned)((a.B + ppw - 1) / ppw));
+#define CPMPC_FUSED(LV, SPV)                                                                                \
+  if (L == LV && SP == SPV) {                                                                               \
+    hipLaunchKernelGGL((fused_sqp_kernel<R, M, SPV, LV>), grid, dim3(64), 0, stream, a, max_iters);         \
+    return;                                                                                                 \
+  }
+    CPMPC_FUSED(4, 10)
+    CPMPC_FUSED(8, 5)
+    CPMPC_FUSED(2, 10)
+    CPMPC_FUSED(4, 5)
+#undef CPMPC_FUSED
+  }
+}
+
+extern "C" int cpmpc_set_pipeline(cpmpc_solver* s, int mode) {
+  if (!s) return fail(CPMPC_ERR_INVALID_ARG, "null solver");
+  if (mode != CPMPC_PIPELINE_AUTO && mode != CPMPC_PIPELINE_SPLIT && mode != CPMPC_PIPELINE_FUSED)
+    return fail(CPMPC_ERR_INVALID_ARG, "unknown pipeline mode");
+  if (mode == CPMPC_PIPELINE_FUSED && !fused_built(s->model, s->S - 1, s->SP))
+    return fail(CPMPC_ERR_UNSUPPORTED, "the fused pipeline is not built for model %d with S-1 = %d, state_spacing = %d",
+                s->model, s->S - 1, s->SP);
+  s->pipeline = mode;
+  return CPMPC_OK;
+}
+extern "C" int cpmpc_get_pipeline(const cpmpc_solver* s) {
+  if (!s) return -1;
+  return use_fused(s) ? CPMPC_PIPELINE_FUSED : CPMPC_PIPELINE_SPLIT;
+}
+
 template <typename R, typename M>
 static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* in, const cpmpc_step_outputs* out,
                            hipStream_t stream) {
@@ -528,13 +573,19 @@ static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* 
   hipLaunchKernelGGL((prepare_kernel<R, M>), gridB, dim3(64), 0, stream, a);
   span_end(s, stream, &sp);
 
-  for (int it = 0; it < (int)s->params.max_iterations; ++it) {
-    span_begin(s, CPMPC_KERNEL_LINEARIZE, stream, &sp);
-    launch_linearize<R, M>(a, s->SP, a.zx, a.zu, a.ist, stream);
+  if (use_fused(s)) {
+    span_begin(s, CPMPC_KERNEL_FUSED, stream, &sp);
+    launch_fused<R, M>(a, s->S - 1, s->SP, (int)s->params.max_iterations, stream);
     span_end(s, stream, &sp);
-    span_begin(s, CPMPC_KERNEL_QP_LS, stream, &sp);
-    hipLaunchKernelGGL((qp_ls_kernel<R, M>), gridB, dim3(64), 0, stream, a);
-    span_end(s, stream, &sp);
+  } else {
+    for (int it = 0; it < (int)s->params.max_iterations; ++it) {
+      span_begin(s, CPMPC_KERNEL_LINEARIZE, stream, &sp);
+      launch_linearize<R, M>(a, s->SP, a.zx, a.zu, a.ist, stream);
+      span_end(s, stream, &sp);
+      span_begin(s, CPMPC_KERNEL_QP_LS, stream, &sp);
+      hipLaunchKernelGGL((qp_ls_kernel<R, M>), gridB, dim3(64), 0, stream, a);
+      span_end(s, stream, &sp);
+    }
   }
 
   span_begin(s, CPMPC_KERNEL_FINALIZE, stream, &sp);

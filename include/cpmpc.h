@@ -235,8 +235,21 @@ enum {
   CPMPC_KERNEL_LINEARIZE = 1, /* RK4 + Jacobians over every shooting interval */
   CPMPC_KERNEL_QP_LS = 2,     /* structured QP + merit line search */
   CPMPC_KERNEL_FINALIZE = 3,  /* ComputePredictedStates + outputs */
-  CPMPC_KERNEL_COUNT = 4
+  CPMPC_KERNEL_FUSED = 4,     /* all SQP iterations in one launch (fused pipeline) */
+  CPMPC_KERNEL_COUNT = 5
 };
+
+/* Two implementations of the SQP iterations, same arithmetic:
+ *   CPMPC_PIPELINE_SPLIT  linearize_kernel + qp_ls_kernel per iteration, one problem per lane, the
+ *                         sensitivities stream through HBM between the kernels (any configuration);
+ *   CPMPC_PIPELINE_FUSED  one launch for all iterations, a problem spread over S-1 lanes, sensitivities in
+ *                         registers (built for the single pendulum with (S-1, state_spacing) in
+ *                         {(4,10), (8,5), (2,10), (4,5)});
+ *   CPMPC_PIPELINE_AUTO   fused where built, else split (default).
+ * Returns CPMPC_ERR_UNSUPPORTED if FUSED is requested for a configuration it is not built for. */
+enum { CPMPC_PIPELINE_AUTO = 0, CPMPC_PIPELINE_SPLIT = 1, CPMPC_PIPELINE_FUSED = 2 };
+int cpmpc_set_pipeline(cpmpc_solver* s, int mode);
+int cpmpc_get_pipeline(const cpmpc_solver* s); /* the one a step will actually use: SPLIT or FUSED */
 
 /* When enabled, every kernel launch of cpmpc_step_batch is bracketed by HIP events on the launch
  * stream; cpmpc_profile_read synchronises those events and returns the accumulated device time. */

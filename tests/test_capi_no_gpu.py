@@ -59,7 +59,7 @@ def test_supported_spacings(lib):
 
 def test_kernel_names(lib, pkg):
     names = [lib.cpmpc_kernel_name(i).decode() for i in range(pkg.capi.KERNEL_COUNT)]
-    assert names == ["prepare_kernel", "linearize_kernel", "qp_ls_kernel", "finalize_kernel"]
+    assert names == ["prepare_kernel", "linearize_kernel", "qp_ls_kernel", "finalize_kernel", "fused_sqp_kernel"]
 
 
 def test_create_validates_like_the_reference_constructor(lib, pkg):

@@ -455,5 +455,68 @@ def test_profiling_counts_launches(pkg):
         opt.step(T(random_states(rng, B), torch.float32), DYN_UI, 0.0)
     prof = opt.profile_read()
     assert prof["prepare_kernel"][1] == 3 and prof["finalize_kernel"][1] == 3
-    assert prof["linearize_kernel"][1] == 15 and prof["qp_ls_kernel"][1] == 15
-    assert all(ms > 0 for ms, _ in prof.values())
+    assert prof["fused_sqp_kernel"][1] == 3 and prof["linearize_kernel"][1] == 0   # auto -> fused here
+    opt.set_pipeline("split")
+    opt.profile_reset()
+    for _ in range(3):
+        opt.step(T(random_states(rng, B), torch.float32), DYN_UI, 0.0)
+    prof = opt.profile_read()
+    assert prof["linearize_kernel"][1] == 15 and prof["qp_ls_kernel"][1] == 15 and prof["fused_sqp_kernel"][1] == 0
+    assert all(ms > 0 for name, (ms, _) in prof.items() if name != "fused_sqp_kernel")
+
+
+# ------------------------------------------------------------------------------------------------
+# the two pipelines (include/cpmpc.h: CPMPC_PIPELINE_*) implement the same arithmetic
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("over", [dict(NO_TOL), dict(), dict(state_spacing=5, max_iterations=6),
+                                  dict(window_length=20, max_iterations=6),
+                                  dict(window_length=20, state_spacing=5, max_iterations=6)])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_fused_and_split_pipelines_agree(pkg, orc, over, dtype):
+    rng = np.random.default_rng(77)
+    B = 777  # not a multiple of the problems-per-wave of any group size
+    x0 = random_states(rng, B)
+    x0[1, ::3] = np.pi / 2 + rng.uniform(-0.4, 0.4, len(x0[1, ::3]))
+    outs = {}
+    for mode in ("split", "fused"):
+        opt = pkg.BatchOptimization(pkg.default_params(**over), max_batch=B, dtype=dtype, device=0)
+        opt.set_pipeline(mode)
+        assert opt.pipeline() == mode
+        o1 = opt.step(T(x0, dtype), DYN_UI, 0.1)
+        u1, st1 = o1.u.clone(), o1.status.clone()
+        o2 = opt.step(T(x0, dtype) * 1.0, DYN_UI, 0.1)  # a warm-started second step through the same pipeline
+        outs[mode] = (u1, st1, o1.iterations.clone(), o1.ls_evals.clone(), o2.u.clone(), o2.status.clone(),
+                      opt.get_solution(B))
+    a, b = outs["split"], outs["fused"]
+    same = (a[1] == b[1]) & (a[2] == b[2]) & (a[3] == b[3])
+    if dtype == torch.float64:
+        assert same.float().mean().item() > 0.995
+        d1 = (a[0] - b[0]).abs().max(dim=0).values[same]
+        assert d1.max().item() < 1e-6
+        same2 = same & (a[5] == b[5])
+        assert ((a[4] - b[4]).abs().max(dim=0).values[same2] < 1e-5).float().mean().item() > 0.99
+        assert (a[6] - b[6]).abs().max(dim=0).values[same2].median().item() < 1e-9
+        # and both agree with the oracle
+        u_cpu, _, st_cpu, _, _ = orc.step_batch_cold(orc.default_opt_params(**over), DYN_UI, 0.1, x0)
+        ok = N_(b[1]) == st_cpu
+        assert ok.mean() > 0.995 and np.abs(N_(b[0]) - u_cpu).max(axis=0)[ok].max() < 1e-5
+    else:
+        # fp32: the group-sum tree of the fused pipeline rounds differently from the split pipeline's serial
+        # sums, which flips near-tie Armijo / exit decisions on a minority of lanes
+        assert same.float().mean().item() > 0.75
+        d1 = (a[0] - b[0]).abs().max(dim=0).values[same]
+        assert d1.median().item() < 1e-2
+
+
+def test_pipeline_selection(pkg):
+    opt = pkg.BatchOptimization(pkg.default_params(), max_batch=64, dtype=torch.float32, device=0)
+    assert opt.pipeline() == "fused"                   # (S-1, state_spacing) = (4, 10) is built
+    opt.set_pipeline("split")
+    assert opt.pipeline() == "split"
+    opt2 = pkg.BatchOptimization(pkg.default_params(state_spacing=20), max_batch=64, dtype=torch.float32, device=0)
+    assert opt2.pipeline() == "split"
+    with pytest.raises(pkg.CpmpcError) as ei:
+        opt2.set_pipeline("fused")
+    assert ei.value.code == pkg.capi.ERR_UNSUPPORTED
+    opt3 = pkg.BatchOptimization(pkg.default_params(), max_batch=64, dtype=torch.float32, device=0, model="double")
+    assert opt3.pipeline() == "split"
