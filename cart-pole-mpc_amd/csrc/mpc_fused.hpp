@@ -47,13 +47,16 @@ __device__ __forceinline__ R from_lane(R v, int src) {
 #define CPMPC_FUSED_BOUNDS __launch_bounds__(64)
 #endif
 
-template <typename R, typename M, int SP, int L>
+// SHARED: the batch shares one parameter set -> the model constants stay wave-uniform (scalar registers)
+template <typename R, typename M, int SP, int L, bool SHARED>
 __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, const int max_iters) {
   constexpr int NX = M::NX;
   constexpr int PPW = 64 / L;  // problems per wave
   __shared__ R lds_u[SP * 64];
   __shared__ R lds_du[SP * 64];
   __shared__ XV<R, NX> lds_G[SP * 64];  // column i of my Gamma_s at [i*64 + lane]
+  __shared__ R lds_gw[SP * 64];         // (U^-1 g)_k of my controls
+  __shared__ R lds_id[SP * 64];         // 1/d_k of my controls
   const int lane = threadIdx.x;
   const int s = lane % L;            // my shooting interval
   const int gbase = lane - s;        // first lane of my group
@@ -63,7 +66,9 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
   const unsigned p = (unsigned)pp;
   const int64_t st = a.stride;
   const int N = a.N;
-  const typename M::Consts k = load_consts(a, p);
+  typename M::Consts k_lane;
+  if constexpr (!SHARED) k_lane = load_consts(a, p);
+  const typename M::Consts& k = SHARED ? a.consts : k_lane;
   const ExtForce<R> fe{R(0), R(0), R(0)};
   const R wu2 = a.wu * a.wu, wd2 = a.wd * a.wd;
   const int right = (s + 1 < L) ? lane + 1 : lane;
@@ -157,8 +162,8 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
     // Systolic: in each of the L passes EVERY lane runs its block from its carry-in {Psi, w_{k+1}, gw_{k+1},
     // d_{k+1}} and then takes its right neighbour's carry-out.  Lane L-1's carry-in is the constant start, so
     // after pass j the lanes L-1 ... L-j hold their final block (recomputing with an unchanged carry-in is
-    // idempotent); no lane-conditional writes, which the register allocator handles far better.
-    R Tgw[SP], Tup[SP], Tid[SP];
+    // idempotent).  Per-control results (gw_k, 1/d_k) go to lane-private LDS, so the loops stay rolled and
+    // there are no lane-conditional register writes.
     R Sm[NX][NX], rho[NX], ha[NX];
     R f_part = R(0), cn_part = R(0);
     bool pd_ok = true;
@@ -179,7 +184,6 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
 #pragma unroll
       for (int i = 0; i < NX; ++i) {
         rho[i] = R(0);
-        ha[i] = R(0);
         wprev[i] = wprev_in[i];
 #pragma unroll
         for (int j = 0; j < NX; ++j) {
@@ -190,10 +194,10 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
       gwprev = gw_in;
       d_next = d_in;
       R u_hi = u_right;
-#pragma unroll
+      R u_cur = lds_u[(SP - 1) * 64 + lane];
+#pragma unroll 1
       for (int i = SP - 1; i >= 0; --i) {
         const int kk = s * SP + i;
-        const R u_cur = lds_u[i * 64 + lane];
         const R u_lo = (i > 0) ? lds_u[(i - 1) * 64 + lane] : u_left;
         const R ru = a.wu * u_cur, rd = a.wd * (u_lo - u_cur);
         f_part += ru * ru + rd * rd;
@@ -216,9 +220,8 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
           wk[r] = m - ups * wprev[r];
         }
         const R gw = g - ups * gwprev;
-        Tgw[i] = gw;
-        Tup[i] = ups;
-        Tid[i] = inv_d;
+        lds_gw[i * 64 + lane] = gw;
+        lds_id[i * 64 + lane] = inv_d;
 #pragma unroll
         for (int i2 = 0; i2 < NX; ++i2) {
           const R wi = wk[i2] * inv_d;
@@ -230,6 +233,7 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
         for (int r = 0; r < NX; ++r) wprev[r] = wk[r];
         gwprev = gw;
         u_hi = u_cur;
+        u_cur = u_lo;
       }
       // my defect: |c|_1 and Psi_s c_s; then Psi <- Psi Phi_s
 #pragma unroll
@@ -275,6 +279,8 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
         d_in = edge ? d_in : v2;
       }
     }
+    // upsilon_k = -wd2 / d_{k+1}: inside a block from my own 1/d, at its end from my right neighbour's first
+    const R id_right = from_lane(lds_id[0 * 64 + lane], right);  // unused for s = L-1
 
     // ---- initial-state rows (node 0), terminal rows (node S-1), group sums ---------------------------------
     R ci[NX], e_term[NX];
@@ -365,7 +371,7 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
 
     // ================= sweep 1b, down the intervals: v_k = D^-1 U^-1 (-(g + R^T q)) without storing W ======
     //   W_k q = omega_k,  omega_k = psi_s . Gamma_k - ups_k omega_{k+1},  psi_s = Psi_s^T q,  psi_{s-1} = Phi_s^T psi_s
-    R Tv[SP];
+    //   v_k is parked in lds_du[k] (sweep 2 turns it into du_k in place)
     {
       R psi_in[NX], om_in = R(0);
 #pragma unroll
@@ -373,15 +379,20 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
 #pragma unroll 1
       for (int pass = 0; pass < L; ++pass) {
         R om = om_in;
-#pragma unroll
+        R id_next = id_right;  // 1/d_{k+1}
+#pragma unroll 1
         for (int i = SP - 1; i >= 0; --i) {
+          const int kk = s * SP + i;
           R Gi[NX];
           unpack<R, NX>(lds_G[i * 64 + lane], Gi);
           R pg = psi_in[0] * Gi[0];
 #pragma unroll
           for (int m = 1; m < NX; ++m) pg += psi_in[m] * Gi[m];
-          om = pg - Tup[i] * om;
-          Tv[i] = -(Tgw[i] + om) * Tid[i];
+          const R idk = lds_id[i * 64 + lane];
+          const R ups = (kk < N - 1) ? (-wd2 * id_next) : R(0);
+          om = pg - ups * om;
+          lds_du[i * 64 + lane] = -(lds_gw[i * 64 + lane] + om) * idk;
+          id_next = idk;
         }
         R psi_out[NX];
 #pragma unroll
@@ -404,65 +415,66 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
       }
     }
 
-    // ================= sweep 2, up the intervals (systolic, as sweep 1) =====================================
+    // ================= sweep 2, up the intervals ==========================================================
+    // Each lane works once, in its turn (v_k -> du_k happens in place in LDS, so no recomputation here); it
+    // hands {dx_{s+1}, du, upsilon of its last control} to its right neighbour.
     R dxs[NX], dxe[NX];
     R gd_part = R(0), curv_part = R(0);
-    R du_in = R(0), ups_in = R(0);      // carry-in: du_{k-1}, upsilon_{k-1} of my first control
-    R du_prev = R(0), ups_prev = R(0);  // carry-out
+    R du_prev = R(0), ups_prev = R(0);
 #pragma unroll
     for (int t = 0; t < NX; ++t) {
-      dxs[t] = -ci[t];  // interval 0's constant start; the others take theirs from the left
+      dxs[t] = -ci[t];  // interval 0's start; the others receive theirs from the left
       dxe[t] = R(0);
     }
 #pragma unroll 1
-    for (int pass = 0; pass < L; ++pass) {
-      gd_part = R(0);
-      curv_part = R(0);
-      du_prev = du_in;
-      ups_prev = ups_in;
-      R acc[NX];
+    for (int turn = 0; turn < L; ++turn) {
+      if (s == turn) {
+        R acc[NX];
 #pragma unroll
-      for (int r = 0; r < NX; ++r) {
-        R v = cdef[r];
+        for (int r = 0; r < NX; ++r) {
+          R v = cdef[r];
 #pragma unroll
-        for (int m = 0; m < NX; ++m) v += Phi[r][m] * dxs[m];
-        acc[r] = v;
+          for (int m = 0; m < NX; ++m) v += Phi[r][m] * dxs[m];
+          acc[r] = v;
+        }
+        R u_lo = u_left;
+        R u_cur = lds_u[0 * 64 + lane];
+#pragma unroll 1
+        for (int i = 0; i < SP; ++i) {
+          const int kk = s * SP + i;
+          const R du = lds_du[i * 64 + lane] - ups_prev * du_prev;
+          lds_du[i * 64 + lane] = du;
+          R Gi[NX];
+          unpack<R, NX>(lds_G[i * 64 + lane], Gi);
+#pragma unroll
+          for (int r = 0; r < NX; ++r) acc[r] += Gi[r] * du;
+          // control-cost gradient g_k, recomputed from u exactly as in sweep 1
+          const R u_hi = (i + 1 < SP) ? lds_u[(i + 1) * 64 + lane] : u_right;
+          R g = wu2 * u_cur + wd2 * (u_cur - u_lo);
+          if (kk < N - 1) g += wd2 * (u_cur - u_hi);
+          gd_part += g * du;
+          const R jd = a.wd * (du_prev - du);
+          curv_part += wu2 * du * du + jd * jd + lam * du * du;
+          du_prev = du;
+          // upsilon_k = -wd2 / d_{k+1}
+          const R id_next = (i + 1 < SP) ? lds_id[(i + 1) * 64 + lane] : id_right;
+          ups_prev = (kk < N - 1) ? (-wd2 * id_next) : R(0);
+          u_lo = u_cur;
+          u_cur = u_hi;
+        }
+#pragma unroll
+        for (int t = 0; t < NX; ++t) dxe[t] = acc[t];
       }
-      R u_lo = u_left;
-      R u_cur = lds_u[0 * 64 + lane];
-#pragma unroll
-      for (int i = 0; i < SP; ++i) {
-        const int kk = s * SP + i;
-        const R du = Tv[i] - ups_prev * du_prev;
-        lds_du[i * 64 + lane] = du;
-        R Gi[NX];
-        unpack<R, NX>(lds_G[i * 64 + lane], Gi);
-#pragma unroll
-        for (int r = 0; r < NX; ++r) acc[r] += Gi[r] * du;
-        // control-cost gradient g_k, recomputed from u exactly as in sweep 1
-        const R u_hi = (i + 1 < SP) ? lds_u[(i + 1) * 64 + lane] : u_right;
-        R g = wu2 * u_cur + wd2 * (u_cur - u_lo);
-        if (kk < N - 1) g += wd2 * (u_cur - u_hi);
-        gd_part += g * du;
-        const R jd = a.wd * (du_prev - du);
-        curv_part += wu2 * du * du + jd * jd + lam * du * du;
-        du_prev = du;
-        ups_prev = Tup[i];
-        u_lo = u_cur;
-        u_cur = u_hi;
-      }
-#pragma unroll
-      for (int t = 0; t < NX; ++t) dxe[t] = acc[t];
-      if (pass + 1 < L) {
-        const bool edge = (s == 0);
+      if (turn + 1 < L) {
+        const bool take = (s == turn + 1);
 #pragma unroll
         for (int t = 0; t < NX; ++t) {
           const R v = from_lane(dxe[t], left);
-          dxs[t] = edge ? dxs[t] : v;
+          dxs[t] = take ? v : dxs[t];
         }
         const R v1 = from_lane(du_prev, left), v2 = from_lane(ups_prev, left);
-        du_in = edge ? du_in : v1;
-        ups_in = edge ? ups_in : v2;
+        du_prev = take ? v1 : du_prev;
+        ups_prev = take ? v2 : ups_prev;
       }
     }
     R gd = group_sum<R, L>(gd_part), curv = group_sum<R, L>(curv_part);

@@ -391,15 +391,17 @@ def test_full_size_properties_fp32(pkg, orc):
     small = pkg.BatchOptimization(pkg.default_params(**NO_TOL), max_batch=4096, dtype=torch.float32, device=0)
     outs = small.step(x0t[:, idx].contiguous(), DYN_UI, 0.0)
     assert torch.equal(outs.u, u[:, idx])
-    # predicted states are the single-shooting rollout of u (optimization.cc:353-371), re-derived with
-    # the RK4 entry point
+    # predicted states are the single-shooting rollout of u (optimization.cc:353-371): every predicted
+    # state is one RK4 step (+ mod_pi) from the one before it, re-derived with the RK4 entry point.  Checked
+    # step by step, so fp32 rounding is not amplified through 40 steps of fast dynamics (|u| up to 300).
     x = x0t[:, :8192].contiguous()
     for k in range(40):
         x = pkg.rk4_batch(DYN_UI, x, u[k, :8192].contiguous(), 0.01, jacobians=False)
         x[1] = torch.remainder(x[1] + np.pi, 2 * np.pi) - np.pi
         d = (x - pred[k, :, :8192])
         d[1] = torch.remainder(d[1] + np.pi, 2 * np.pi) - np.pi
-        assert d.abs().max().item() < 2e-3, k
+        assert (d.abs() <= 2e-5 * (1.0 + x.abs())).all(), k
+        x = pred[k, :, :8192].contiguous()
     # fp32 against the fp64 oracle on a sample: report, bound loosely (the reference is fp64-only)
     samp = np.arange(0, B, B // 256)[:256]
     u_cpu, _, _, _, _ = orc.step_batch_cold(orc.default_opt_params(**NO_TOL), DYN_UI, 0.0, x0[:, samp])
