@@ -925,3 +925,15 @@ extern "C" int cpmpc_sim_step_batch_host(int64_t B, const double* dyn_shared_hos
   if (e != hipSuccess) return fail(CPMPC_ERR_HIP, "HIP copy failed: %s", hipGetErrorString(e));
   return CPMPC_OK;
 }
+
+#ifdef CPMPC_FUSED_TIMING
+// debug build only: read and clear the per-phase cycle counters of fused_sqp_kernel
+extern "C" int cpmpc_debug_phase_cycles(unsigned long long* out8) {
+  hipDeviceSynchronize();
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(cpmpc::g_fused_phase_cycles), 8 * sizeof(unsigned long long)) != hipSuccess)
+    return -1;
+  unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  hipMemcpyToSymbol(HIP_SYMBOL(cpmpc::g_fused_phase_cycles), zero, sizeof(zero));
+  return 0;
+}
+#endif

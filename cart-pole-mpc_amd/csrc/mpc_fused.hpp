@@ -38,13 +38,34 @@ __device__ __forceinline__ R from_lane(R v, int src) {
   return __shfl(v, src);
 }
 
-#ifndef CPMPC_FUSED_WAVES
-#define CPMPC_FUSED_WAVES 0
+// Waves per SIMD the register allocator must leave room for.  The sweeps are latency chains (LDS round trips,
+// lane shuffles), so a second resident wave is worth a few spilled dwords in fp32 (measured +15%); fp64 values
+// take two registers each and stay at one wave.
+#ifndef CPMPC_FUSED_WAVES_F32
+#define CPMPC_FUSED_WAVES_F32 2
 #endif
-#if CPMPC_FUSED_WAVES > 0
-#define CPMPC_FUSED_BOUNDS __launch_bounds__(64, CPMPC_FUSED_WAVES)
+#define CPMPC_FUSED_BOUNDS __launch_bounds__(64, (sizeof(R) == 4 ? CPMPC_FUSED_WAVES_F32 : 1))
+
+// Debug build only (-DCPMPC_FUSED_TIMING): shader-clock cycles per phase, summed over waves, read back by
+// cpmpc_debug_phase_cycles().  Not part of the product library.
+#ifdef CPMPC_FUSED_TIMING
+__device__ unsigned long long g_fused_phase_cycles[8];
+#define CPMPC_TICK_INIT() unsigned long long tick_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tick_last = __builtin_readcyclecounter()
+#define CPMPC_TICK(IDX)                                              \
+  do {                                                               \
+    const unsigned long long tick_now = __builtin_readcyclecounter(); \
+    tick_acc[IDX] += tick_now - tick_last;                           \
+    tick_last = tick_now;                                            \
+  } while (0)
+#define CPMPC_TICK_FLUSH()                                                                       \
+  do {                                                                                           \
+    if (threadIdx.x == 0)                                                                        \
+      for (int ti = 0; ti < 8; ++ti) atomicAdd(&g_fused_phase_cycles[ti], tick_acc[ti]);         \
+  } while (0)
 #else
-#define CPMPC_FUSED_BOUNDS __launch_bounds__(64)
+#define CPMPC_TICK_INIT() do { } while (0)
+#define CPMPC_TICK(IDX) do { } while (0)
+#define CPMPC_TICK_FLUSH() do { } while (0)
 #endif
 
 // SHARED: the batch shares one parameter set -> the model constants stay wave-uniform (scalar registers)
@@ -57,6 +78,7 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
   __shared__ XV<R, NX> lds_G[SP * 64];  // column i of my Gamma_s at [i*64 + lane]
   __shared__ R lds_gw[SP * 64];         // (U^-1 g)_k of my controls
   __shared__ R lds_id[SP * 64];         // 1/d_k of my controls
+  CPMPC_TICK_INIT();
   const int lane = threadIdx.x;
   const int s = lane % L;            // my shooting interval
   const int gbase = lane - s;        // first lane of my group
@@ -101,6 +123,7 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
     if (!__any(status == kTermNone)) break;
     const bool live = (status == kTermNone);
 
+    CPMPC_TICK(7);
     // ================= linearise my interval (optimization.cc:99-160) ==================================
     R Phi[NX][NX], cdef[NX];
     {
@@ -152,100 +175,134 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
       wrap_angles<R, M>(cdef);
     }
 
+    CPMPC_TICK(0);
     // neighbours' boundary controls (u_{k-1} of my first control, u_{k+1} of my last one)
     const R u_first = lds_u[0 * 64 + lane], u_last = lds_u[(SP - 1) * 64 + lane];
     R u_left = from_lane(u_last, left);
     if (s == 0) u_left = u_prev;
     const R u_right = from_lane(u_first, right);  // unused for s = L-1
 
-    // ================= sweep 1, down the intervals =====================================================
-    // Systolic: in each of the L passes EVERY lane runs its block from its carry-in {Psi, w_{k+1}, gw_{k+1},
-    // d_{k+1}} and then takes its right neighbour's carry-out.  Lane L-1's carry-in is the constant start, so
-    // after pass j the lanes L-1 ... L-j hold their final block (recomputing with an unchanged carry-in is
-    // idempotent).  Per-control results (gw_k, 1/d_k) go to lane-private LDS, so the loops stay rolled and
-    // there are no lane-conditional register writes.
-    R Sm[NX][NX], rho[NX], ha[NX];
-    R f_part = R(0), cn_part = R(0);
+    // ================= block-parallel sweeps ===============================================================
+    // All three sweeps of the structured QP are linear recurrences in k, so every lane first solves its own
+    // block in block-local coordinates (carry-in = 0) together with the scalar chain e_k that says how a
+    // carry-in would propagate; a short chain over the L lanes then fixes the true block-boundary values and
+    // each lane corrects its block locally:
+    //     w_k  = Psi_s wt_k + e_k w_in,      gw_k = gwt_k + e_k gw_in,      e_k = -ups_k e_{k+1}
+    //     wt_k = Gamma_k - ups_k wt_{k+1},   gwt_k = g_k - ups_k gwt_{k+1}  (wt, gwt = 0 and e = 1 past the block)
+    // with Psi_s = diag(w) Phi_{S-2} ... Phi_{s+1} constant inside a block.
+
+    // ---- pivots d_k = diag_k - wd2^2 / d_{k+1} of T = U D U^T: they depend on (lambda, weights) only, so every
+    //      lane runs the whole chain and keeps 1/d of its own block (lane-private LDS) -------------------------
     bool pd_ok = true;
-    R Psi_in[NX][NX], wprev_in[NX], gw_in = R(0), d_in = R(1);    // carry-in  (from interval s+1)
-    R Psi[NX][NX], wprev[NX], gwprev = R(0), d_next = R(1);       // carry-out (to interval s-1)
-#pragma unroll
-    for (int r = 0; r < NX; ++r) {
-      wprev_in[r] = R(0);
-#pragma unroll
-      for (int c = 0; c < NX; ++c) Psi_in[r][c] = (r == c) ? Rw[r] : R(0);
-    }
+    R id_right = R(0);  // 1/d of the first control after my block (unused for s = L-1)
+    {
+      R idn = R(0);
 #pragma unroll 1
-    for (int pass = 0; pass < L; ++pass) {
-      // block-local accumulators: the last pass is the one that counts
-      f_part = R(0);
-      cn_part = R(0);
-      pd_ok = true;
-#pragma unroll
-      for (int i = 0; i < NX; ++i) {
-        rho[i] = R(0);
-        wprev[i] = wprev_in[i];
-#pragma unroll
-        for (int j = 0; j < NX; ++j) {
-          Sm[i][j] = R(0);
-          Psi[i][j] = Psi_in[i][j];
+      for (int sb = L - 1; sb >= 0; --sb) {
+        if (sb == s) id_right = idn;
+#pragma unroll 1
+        for (int i = SP - 1; i >= 0; --i) {
+          const int kk = sb * SP + i;
+          const R nd = (kk < N - 1 ? R(1) : R(0)) + R(1);
+          const R ups = (kk < N - 1) ? (-wd2 * idn) : R(0);
+          const R dk = (wu2 + lam + wd2 * nd) + wd2 * ups;
+          if (!(dk > R(0))) pd_ok = false;
+          idn = Math<R>::rcp(dk);
+          if (sb == s) lds_id[i * 64 + lane] = idn;
         }
       }
-      gwprev = gw_in;
-      d_next = d_in;
+    }
+
+    // ---- sweep 1, local pass down my block ---------------------------------------------------------------
+    R Sm[NX][NX], rho[NX], ha[NX];
+    R f_part = R(0), cn_part = R(0);
+    R wt[NX], gwt = R(0), e_blk = R(1);  // after the pass: wt_0, gwt_0, e_0 of my block
+    R Psi[NX][NX], w_in[NX], gw_in = R(0);  // my block's carry-in (exact after the boundary chain)
+    R ci[NX], e_term[NX];
+    {
+      R St[NX][NX], tt[NX], rr[NX], eps = R(0), sig = R(0);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        wt[i] = R(0);
+        tt[i] = R(0);
+        rr[i] = R(0);
+#pragma unroll
+        for (int j = 0; j < NX; ++j) St[i][j] = R(0);
+      }
       R u_hi = u_right;
       R u_cur = lds_u[(SP - 1) * 64 + lane];
+      R idn = id_right;
 #pragma unroll 1
       for (int i = SP - 1; i >= 0; --i) {
         const int kk = s * SP + i;
         const R u_lo = (i > 0) ? lds_u[(i - 1) * 64 + lane] : u_left;
         const R ru = a.wu * u_cur, rd = a.wd * (u_lo - u_cur);
         f_part += ru * ru + rd * rd;
-        const R nd = (kk < N - 1 ? R(1) : R(0)) + R(1);
-        const R diag = wu2 + lam + wd2 * nd;
         R g = wu2 * u_cur + wd2 * (u_cur - u_lo);
         if (kk < N - 1) g += wd2 * (u_cur - u_hi);
-        const R ups = (kk < N - 1) ? (-wd2 / d_next) : R(0);
-        const R dk = diag + wd2 * ups;
-        if (!(dk > R(0))) pd_ok = false;
-        const R inv_d = R(1) / dk;
-        d_next = dk;
-        R wk[NX], Gi[NX];
+        const R ups = (kk < N - 1) ? (-wd2 * idn) : R(0);
+        const R idk = lds_id[i * 64 + lane];
+        R Gi[NX];
         unpack<R, NX>(lds_G[i * 64 + lane], Gi);
 #pragma unroll
-        for (int r = 0; r < NX; ++r) {
-          R m = Psi[r][0] * Gi[0];
-#pragma unroll
-          for (int c = 1; c < NX; ++c) m += Psi[r][c] * Gi[c];
-          wk[r] = m - ups * wprev[r];
-        }
-        const R gw = g - ups * gwprev;
-        lds_gw[i * 64 + lane] = gw;
-        lds_id[i * 64 + lane] = inv_d;
+        for (int r = 0; r < NX; ++r) wt[r] = Gi[r] - ups * wt[r];
+        gwt = g - ups * gwt;
+        e_blk = -ups * e_blk;
+        lds_gw[i * 64 + lane] = gwt;
+        const R ei = e_blk * idk;
+        eps += ei * e_blk;
+        sig += ei * gwt;
 #pragma unroll
         for (int i2 = 0; i2 < NX; ++i2) {
-          const R wi = wk[i2] * inv_d;
-          rho[i2] += wi * gw;
+          const R wi = wt[i2] * idk;
+          tt[i2] += wi * e_blk;
+          rr[i2] += wi * gwt;
 #pragma unroll
-          for (int j2 = 0; j2 <= i2; ++j2) Sm[i2][j2] += wi * wk[j2];
+          for (int j2 = 0; j2 <= i2; ++j2) St[i2][j2] += wi * wt[j2];
         }
-#pragma unroll
-        for (int r = 0; r < NX; ++r) wprev[r] = wk[r];
-        gwprev = gw;
+        idn = idk;
         u_hi = u_cur;
         u_cur = u_lo;
       }
-      // my defect: |c|_1 and Psi_s c_s; then Psi <- Psi Phi_s
 #pragma unroll
       for (int t = 0; t < NX; ++t) cn_part += Math<R>::fabs(cdef[t]);
+
+      // ---- initial-state residual (node 0) and terminal residual (node S-1), replicated ---------------------
+      {
+        R x0n[NX], xT[NX];
+#pragma unroll
+        for (int t = 0; t < NX; ++t) {
+          x0n[t] = from_lane(xs[t], gbase);
+          xT[t] = from_lane(xe[t], gbase + L - 1);
+          ci[t] = x0n[t] - xm[t];
+          e_term[t] = xT[t] - tgt[t];
+        }
+        wrap_angles<R, M>(ci);
+        wrap_angles<R, M>(e_term);
+      }
+      // ---- boundary chain, down the lanes: Psi_s, w_in, gw_in ---------------------------------------------
 #pragma unroll
       for (int r = 0; r < NX; ++r) {
-        R acc = Psi[r][0] * cdef[0];
+        w_in[r] = R(0);
 #pragma unroll
-        for (int m = 1; m < NX; ++m) acc += Psi[r][m] * cdef[m];
-        ha[r] = acc;
+        for (int c = 0; c < NX; ++c) Psi[r][c] = (r == c) ? Rw[r] : R(0);
       }
-      {
+#pragma unroll 1
+      for (int round = 0; round + 1 < L; ++round) {
+        // my block's values at its first control, from my current carry-in (exact once the carry-in is)
+        const bool edge = (s == L - 1);
+#pragma unroll
+        for (int r = 0; r < NX; ++r) {
+          R wo = e_blk * w_in[r];
+#pragma unroll
+          for (int m = 0; m < NX; ++m) wo += Psi[r][m] * wt[m];
+          const R v = from_lane(wo, right);
+          w_in[r] = edge ? w_in[r] : v;
+        }
+        {
+          const R v = from_lane(gwt + e_blk * gw_in, right);
+          gw_in = edge ? gw_in : v;
+        }
         R T[NX][NX];
 #pragma unroll
         for (int r = 0; r < NX; ++r)
@@ -259,52 +316,62 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
 #pragma unroll
         for (int r = 0; r < NX; ++r)
 #pragma unroll
-          for (int c = 0; c < NX; ++c) Psi[r][c] = T[r][c];
+          for (int c = 0; c < NX; ++c) {
+            const R v = from_lane(T[r][c], right);
+            Psi[r][c] = edge ? Psi[r][c] : v;
+          }
       }
-      // take the right neighbour's carry-out as my carry-in (the last interval keeps the constant start)
-      if (pass + 1 < L) {
-        const bool edge = (s == L - 1);
+      // ---- combine: S_s = sum_k w_k w_k^T / d_k,  rho_s = sum_k w_k gw_k / d_k,  ha_s = Psi_s c_s ----------------
+      {
+        R hvv[NX];
 #pragma unroll
         for (int r = 0; r < NX; ++r) {
+          R acc = Phi[r][0] * ci[0];
 #pragma unroll
-          for (int c = 0; c < NX; ++c) {
-            const R v = from_lane(Psi[r][c], right);
-            Psi_in[r][c] = edge ? Psi_in[r][c] : v;
-          }
-          const R v = from_lane(wprev[r], right);
-          wprev_in[r] = edge ? wprev_in[r] : v;
+          for (int m = 1; m < NX; ++m) acc += Phi[r][m] * ci[m];
+          hvv[r] = cdef[r] - ((s == 0) ? acc : R(0));  // dx_0 = -c_init enters through interval 0
         }
-        const R v1 = from_lane(gwprev, right), v2 = from_lane(d_next, right);
-        gw_in = edge ? gw_in : v1;
-        d_in = edge ? d_in : v2;
+#pragma unroll
+        for (int r = 0; r < NX; ++r) {
+          R acc = Psi[r][0] * hvv[0];
+#pragma unroll
+          for (int m = 1; m < NX; ++m) acc += Psi[r][m] * hvv[m];
+          ha[r] = acc;
+        }
       }
+      R PT[NX], PS[NX][NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        R acc = Psi[i][0] * tt[0];
+        R acr = Psi[i][0] * rr[0];
+#pragma unroll
+        for (int m = 1; m < NX; ++m) {
+          acc += Psi[i][m] * tt[m];
+          acr += Psi[i][m] * rr[m];
+        }
+        PT[i] = acc;
+        rho[i] = acr + acc * gw_in + w_in[i] * (sig + eps * gw_in);
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+          R v = Psi[i][0] * (j <= 0 ? St[0][j] : St[j][0]);
+#pragma unroll
+          for (int m = 1; m < NX; ++m) v += Psi[i][m] * (j <= m ? St[m][j] : St[j][m]);
+          PS[i][j] = v;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NX; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+          R v = PS[i][0] * Psi[j][0];
+#pragma unroll
+          for (int m = 1; m < NX; ++m) v += PS[i][m] * Psi[j][m];
+          Sm[i][j] = v + PT[i] * w_in[j] + w_in[i] * (PT[j] + eps * w_in[j]);
+        }
     }
-    // upsilon_k = -wd2 / d_{k+1}: inside a block from my own 1/d, at its end from my right neighbour's first
-    const R id_right = from_lane(lds_id[0 * 64 + lane], right);  // unused for s = L-1
 
-    // ---- initial-state rows (node 0), terminal rows (node S-1), group sums ---------------------------------
-    R ci[NX], e_term[NX];
-    {
-      R x0n[NX], xT[NX];
-#pragma unroll
-      for (int t = 0; t < NX; ++t) {
-        x0n[t] = from_lane(xs[t], gbase);
-        xT[t] = from_lane(xe[t], gbase + L - 1);
-        ci[t] = x0n[t] - xm[t];
-        e_term[t] = xT[t] - tgt[t];
-      }
-      wrap_angles<R, M>(ci);
-      wrap_angles<R, M>(e_term);
-    }
-    if (s == 0) {  // Psi in lane 0 is now diag(w) Phi_{S-2}...Phi_0: contribution of dx_0 = -c_init
-#pragma unroll
-      for (int r = 0; r < NX; ++r) {
-        R acc = Psi[r][0] * ci[0];
-#pragma unroll
-        for (int m = 1; m < NX; ++m) acc += Psi[r][m] * ci[m];
-        ha[r] -= acc;
-      }
-    }
+    CPMPC_TICK(1);
+    // ---- group sums, terminal rows ------------------------------------------------------------------------
     R f = group_sum<R, L>(f_part), cn = group_sum<R, L>(cn_part);
     R hv[NX];
 #pragma unroll
@@ -314,7 +381,6 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
 #pragma unroll
       for (int j = 0; j <= i; ++j) Sm[i][j] = group_sum<R, L>(Sm[i][j]);
     }
-    pd_ok = (group_sum<R, L>(pd_ok ? R(0) : R(1)) == R(0));  // AND over the group
 #pragma unroll
     for (int t = 0; t < NX; ++t) {
       cn += Math<R>::fabs(ci[t]);
@@ -369,112 +435,114 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
     }
     if (live && status == kTermNone && !pd_ok) status = kTermQpIndefinite;
 
-    // ================= sweep 1b, down the intervals: v_k = D^-1 U^-1 (-(g + R^T q)) without storing W ======
-    //   W_k q = omega_k,  omega_k = psi_s . Gamma_k - ups_k omega_{k+1},  psi_s = Psi_s^T q,  psi_{s-1} = Phi_s^T psi_s
-    //   v_k is parked in lds_du[k] (sweep 2 turns it into du_k in place)
+    CPMPC_TICK(2);
+    // ================= sweep 1b, local pass down my block: v_k = -(gw_k + w_k . q) / d_k ====================
+    //   w_k . q = psi . wt_k + e_k (w_in . q),  psi = Psi_s^T q,  and  psi . wt_k  obeys wt's recurrence, so W is
+    //   never stored.  v_k is parked in lds_du[k]; sweep 2 turns it into du_k in place.
     {
-      R psi_in[NX], om_in = R(0);
+      R psi[NX];
+      R om_in = gw_in;  // gw_in + w_in . q: what a unit of e_k carries into (gw_k + w_k . q)
 #pragma unroll
-      for (int r = 0; r < NX; ++r) psi_in[r] = Rw[r] * q[r];
+      for (int c = 0; c < NX; ++c) {
+        R acc = Psi[0][c] * q[0];
+#pragma unroll
+        for (int r = 1; r < NX; ++r) acc += Psi[r][c] * q[r];
+        psi[c] = acc;
+        om_in += w_in[c] * q[c];
+      }
+      R om = R(0), e = R(1);
+      R idn = id_right;
 #pragma unroll 1
-      for (int pass = 0; pass < L; ++pass) {
-        R om = om_in;
-        R id_next = id_right;  // 1/d_{k+1}
-#pragma unroll 1
-        for (int i = SP - 1; i >= 0; --i) {
-          const int kk = s * SP + i;
-          R Gi[NX];
-          unpack<R, NX>(lds_G[i * 64 + lane], Gi);
-          R pg = psi_in[0] * Gi[0];
+      for (int i = SP - 1; i >= 0; --i) {
+        const int kk = s * SP + i;
+        R Gi[NX];
+        unpack<R, NX>(lds_G[i * 64 + lane], Gi);
+        R pg = psi[0] * Gi[0];
 #pragma unroll
-          for (int m = 1; m < NX; ++m) pg += psi_in[m] * Gi[m];
-          const R idk = lds_id[i * 64 + lane];
-          const R ups = (kk < N - 1) ? (-wd2 * id_next) : R(0);
-          om = pg - ups * om;
-          lds_du[i * 64 + lane] = -(lds_gw[i * 64 + lane] + om) * idk;
-          id_next = idk;
-        }
-        R psi_out[NX];
-#pragma unroll
-        for (int c = 0; c < NX; ++c) {
-          R acc = Phi[0][c] * psi_in[0];
-#pragma unroll
-          for (int r = 1; r < NX; ++r) acc += Phi[r][c] * psi_in[r];
-          psi_out[c] = acc;
-        }
-        if (pass + 1 < L) {
-          const bool edge = (s == L - 1);
-#pragma unroll
-          for (int r = 0; r < NX; ++r) {
-            const R v = from_lane(psi_out[r], right);
-            psi_in[r] = edge ? psi_in[r] : v;
-          }
-          const R v1 = from_lane(om, right);
-          om_in = edge ? om_in : v1;
-        }
+        for (int m = 1; m < NX; ++m) pg += psi[m] * Gi[m];
+        const R idk = lds_id[i * 64 + lane];
+        const R ups = (kk < N - 1) ? (-wd2 * idn) : R(0);
+        om = pg - ups * om;
+        e = -ups * e;
+        lds_du[i * 64 + lane] = -(lds_gw[i * 64 + lane] + om + e * om_in) * idk;
+        idn = idk;
       }
     }
 
-    // ================= sweep 2, up the intervals ==========================================================
-    // Each lane works once, in its turn (v_k -> du_k happens in place in LDS, so no recomputation here); it
-    // hands {dx_{s+1}, du, upsilon of its last control} to its right neighbour.
+    CPMPC_TICK(3);
+    // ================= sweep 2, up the blocks: du_k = v_k - ups_{k-1} du_{k-1},  dx_{s+1} = Phi dx_s + Gamma du + c ====
+    //   local:  dut_k = v_k - ups_{k-1} dut_{k-1},  et_k = -ups_{k-1} et_{k-1}  (dut = 0, et = 1 before the block),
+    //           du_k = dut_k + et_k du_in;  ups_{k-1} = -wd2 / d_k uses my own pivots only
     R dxs[NX], dxe[NX];
     R gd_part = R(0), curv_part = R(0);
-    R du_prev = R(0), ups_prev = R(0);
+    R du_in = R(0);  // du of the control before my block (0 for interval 0: u_prev is fixed)
+    {
+      R Gt[NX], Ht[NX], dut = R(0), et = R(1);
 #pragma unroll
-    for (int t = 0; t < NX; ++t) {
-      dxs[t] = -ci[t];  // interval 0's start; the others receive theirs from the left
-      dxe[t] = R(0);
-    }
+      for (int t = 0; t < NX; ++t) {
+        Gt[t] = cdef[t];
+        Ht[t] = R(0);
+      }
 #pragma unroll 1
-    for (int turn = 0; turn < L; ++turn) {
-      if (s == turn) {
-        R acc[NX];
+      for (int i = 0; i < SP; ++i) {
+        const int kk = s * SP + i;
+        const R upm = (kk > 0) ? (-wd2 * lds_id[i * 64 + lane]) : R(0);
+        dut = lds_du[i * 64 + lane] - upm * dut;
+        et = -upm * et;
+        lds_du[i * 64 + lane] = dut;
+        R Gi[NX];
+        unpack<R, NX>(lds_G[i * 64 + lane], Gi);
 #pragma unroll
         for (int r = 0; r < NX; ++r) {
-          R v = cdef[r];
+          Gt[r] += Gi[r] * dut;
+          Ht[r] += Gi[r] * et;
+        }
+      }
+      // boundary chain, up the lanes: dx_s and du_in
+#pragma unroll
+      for (int t = 0; t < NX; ++t) dxs[t] = -ci[t];  // interval 0's start; the others receive theirs below
+#pragma unroll 1
+      for (int round = 0; round < L; ++round) {
+#pragma unroll
+        for (int r = 0; r < NX; ++r) {
+          R v = Gt[r] + Ht[r] * du_in;
 #pragma unroll
           for (int m = 0; m < NX; ++m) v += Phi[r][m] * dxs[m];
-          acc[r] = v;
+          dxe[r] = v;
         }
-        R u_lo = u_left;
-        R u_cur = lds_u[0 * 64 + lane];
-#pragma unroll 1
-        for (int i = 0; i < SP; ++i) {
-          const int kk = s * SP + i;
-          const R du = lds_du[i * 64 + lane] - ups_prev * du_prev;
-          lds_du[i * 64 + lane] = du;
-          R Gi[NX];
-          unpack<R, NX>(lds_G[i * 64 + lane], Gi);
+        if (round + 1 < L) {
+          const bool edge = (s == 0);
 #pragma unroll
-          for (int r = 0; r < NX; ++r) acc[r] += Gi[r] * du;
-          // control-cost gradient g_k, recomputed from u exactly as in sweep 1
-          const R u_hi = (i + 1 < SP) ? lds_u[(i + 1) * 64 + lane] : u_right;
-          R g = wu2 * u_cur + wd2 * (u_cur - u_lo);
-          if (kk < N - 1) g += wd2 * (u_cur - u_hi);
-          gd_part += g * du;
-          const R jd = a.wd * (du_prev - du);
-          curv_part += wu2 * du * du + jd * jd + lam * du * du;
-          du_prev = du;
-          // upsilon_k = -wd2 / d_{k+1}
-          const R id_next = (i + 1 < SP) ? lds_id[(i + 1) * 64 + lane] : id_right;
-          ups_prev = (kk < N - 1) ? (-wd2 * id_next) : R(0);
-          u_lo = u_cur;
-          u_cur = u_hi;
+          for (int t = 0; t < NX; ++t) {
+            const R v = from_lane(dxe[t], left);
+            dxs[t] = edge ? dxs[t] : v;
+          }
+          const R v1 = from_lane(dut + et * du_in, left);
+          du_in = edge ? du_in : v1;
         }
-#pragma unroll
-        for (int t = 0; t < NX; ++t) dxe[t] = acc[t];
       }
-      if (turn + 1 < L) {
-        const bool take = (s == turn + 1);
-#pragma unroll
-        for (int t = 0; t < NX; ++t) {
-          const R v = from_lane(dxe[t], left);
-          dxs[t] = take ? v : dxs[t];
-        }
-        const R v1 = from_lane(du_prev, left), v2 = from_lane(ups_prev, left);
-        du_prev = take ? v1 : du_prev;
-        ups_prev = take ? v2 : ups_prev;
+      // local correction du_k = dut_k + et_k du_in, slope and curvature of the control rows
+      R du_prev = du_in;
+      R u_lo = u_left;
+      R u_cur = lds_u[0 * 64 + lane];
+      et = R(1);
+#pragma unroll 1
+      for (int i = 0; i < SP; ++i) {
+        const int kk = s * SP + i;
+        const R upm = (kk > 0) ? (-wd2 * lds_id[i * 64 + lane]) : R(0);
+        et = -upm * et;
+        const R du = lds_du[i * 64 + lane] + et * du_in;
+        lds_du[i * 64 + lane] = du;
+        // control-cost gradient g_k, recomputed from u exactly as in sweep 1
+        const R u_hi = (i + 1 < SP) ? lds_u[(i + 1) * 64 + lane] : u_right;
+        R g = wu2 * u_cur + wd2 * (u_cur - u_lo);
+        if (kk < N - 1) g += wd2 * (u_cur - u_hi);
+        gd_part += g * du;
+        const R jd = a.wd * (du_prev - du);
+        curv_part += wu2 * du * du + jd * jd + lam * du * du;
+        du_prev = du;
+        u_lo = u_cur;
+        u_cur = u_hi;
       }
     }
     R gd = group_sum<R, L>(gd_part), curv = group_sum<R, L>(curv_part);
@@ -493,9 +561,9 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
     }
     if (live && status == kTermNone && (!Math<R>::finite(gd) || !Math<R>::finite(curv))) status = kTermQpIndefinite;
     // du of my left neighbour's last control, for the (u_{k-1} - u_k) row of my first control
-    R du_left = from_lane(lds_du[(SP - 1) * 64 + lane], left);
-    if (s == 0) du_left = R(0);
+    const R du_left = du_in;
 
+    CPMPC_TICK(4);
     // ================= penalty, merit slope ==================================================================
     if (cn > R(0)) {
       const R mu_req = (gd + R(0.5) * curv) / ((R(1) - a.rho) * cn);
@@ -585,6 +653,7 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
       }
     }
 
+    CPMPC_TICK(5);
     // ================= accept / reject, step-length memory, damping, termination ===========================
     if (live && status == kTermNone) {
       a_start = R(1);
@@ -626,6 +695,7 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
     }
   }
 
+  CPMPC_TICK(6);
   // ---- write the iterate (= warm start) and the per-problem solver state back -------------------------------
   if (valid) {
     a.zx[(int64_t)s * st + p] = pack<R, NX>(xs);
@@ -644,6 +714,8 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
       a.ist[IS_FAILED * st + p] = failed;
     }
   }
+  CPMPC_TICK(7);
+  CPMPC_TICK_FLUSH();
 }
 
 }  // namespace cpmpc
