@@ -26,16 +26,89 @@
 
 namespace cpmpc {
 
+// ---- 2x2 matrices for the pivot recurrence (compile-time exponent, by squaring) -----------------------------
+template <typename R>
+struct Mat2 {
+  R a, b, c, d;  // [[a, b], [c, d]]
+};
+template <typename R>
+__device__ __forceinline__ Mat2<R> mat2_mul(const Mat2<R>& x, const Mat2<R>& y) {
+  return Mat2<R>{x.a * y.a + x.b * y.c, x.a * y.b + x.b * y.d, x.c * y.a + x.d * y.c, x.c * y.b + x.d * y.d};
+}
+template <typename R, int E>
+__device__ __forceinline__ Mat2<R> mat2_pow(const Mat2<R>& t) {
+  if constexpr (E <= 0) {
+    return Mat2<R>{R(1), R(0), R(0), R(1)};
+  } else if constexpr (E == 1) {
+    return t;
+  } else if constexpr (E % 2 == 0) {
+    const Mat2<R> h = mat2_pow<R, E / 2>(t);
+    return mat2_mul<R>(h, h);
+  } else {
+    return mat2_mul<R>(mat2_pow<R, E - 1>(t), t);
+  }
+}
+
+// ---- lane traffic inside a group ------------------------------------------------------------------------
+// Groups are L consecutive lanes with L | 16, so they never straddle a 16-lane DPP row: neighbour moves are
+// row shifts and, for L = 4 (one quad) and L = 2, sums and broadcasts are quad permutes.  DPP moves are VALU
+// operand modifiers: no trip through the LDS crossbar as for ds_bpermute (__shfl), which matters in the
+// boundary chains where every move is on the critical path.
+template <int CTRL>
+__device__ __forceinline__ int dpp32(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v) {
+  return __builtin_bit_cast(float, dpp32<CTRL>(__builtin_bit_cast(int, v)));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const unsigned lo = (unsigned)dpp32<CTRL>((int)(unsigned)(b & 0xffffffffll));
+  const unsigned hi = (unsigned)dpp32<CTRL>((int)(unsigned)((unsigned long long)b >> 32));
+  return __builtin_bit_cast(double, (long long)(((unsigned long long)hi << 32) | lo));
+}
+constexpr int kDppQuadXor1 = 1 | (0 << 2) | (3 << 4) | (2 << 6);  // quad_perm:[1,0,3,2]
+constexpr int kDppQuadXor2 = 2 | (3 << 2) | (0 << 4) | (1 << 6);  // quad_perm:[2,3,0,1]
+constexpr int kDppRowShl1 = 0x101;                                // lane i reads lane i+1 (inside its row)
+constexpr int kDppRowShr1 = 0x111;                                // lane i reads lane i-1 (inside its row)
+
+// sum over the group, bitwise identical in all its lanes (commutative butterfly)
 template <typename R, int L>
 __device__ __forceinline__ R group_sum(R v) {
+  if constexpr (L == 4) {
+    v += dpp<kDppQuadXor1>(v);
+    v += dpp<kDppQuadXor2>(v);
+  } else if constexpr (L == 2) {
+    v += dpp<kDppQuadXor1>(v);
+  } else {
 #pragma unroll
-  for (int off = 1; off < L; off <<= 1) v += __shfl_xor(v, off);
+    for (int off = 1; off < L; off <<= 1) v += __shfl_xor(v, off);
+  }
   return v;
 }
-// value held by the lane `delta` positions to the right (+) / left (-); callers ignore it at the group edge
+// value of my right / left neighbour lane; callers discard it at the group edge
 template <typename R>
-__device__ __forceinline__ R from_lane(R v, int src) {
-  return __shfl(v, src);
+__device__ __forceinline__ R lane_right(R v) {
+  return dpp<kDppRowShl1>(v);
+}
+template <typename R>
+__device__ __forceinline__ R lane_left(R v) {
+  return dpp<kDppRowShr1>(v);
+}
+// value held by the first / last lane of my group
+template <typename R, int L>
+__device__ __forceinline__ R group_first(R v, int gbase) {
+  if constexpr (L == 4) return dpp<0x00>(v);                              // quad_perm:[0,0,0,0]
+  else if constexpr (L == 2) return dpp<(0 | (0 << 2) | (2 << 4) | (2 << 6))>(v);  // quad_perm:[0,0,2,2]
+  else return __shfl(v, gbase);
+}
+template <typename R, int L>
+__device__ __forceinline__ R group_last(R v, int gbase) {
+  if constexpr (L == 4) return dpp<0xff>(v);                              // quad_perm:[3,3,3,3]
+  else if constexpr (L == 2) return dpp<(1 | (1 << 2) | (3 << 4) | (3 << 6))>(v);  // quad_perm:[1,1,3,3]
+  else return __shfl(v, gbase + L - 1);
 }
 
 // Waves per SIMD the register allocator must leave room for.  The sweeps are latency chains (LDS round trips,
@@ -43,6 +116,10 @@ __device__ __forceinline__ R from_lane(R v, int src) {
 // take two registers each and stay at one wave.
 #ifndef CPMPC_FUSED_WAVES_F32
 #define CPMPC_FUSED_WAVES_F32 2
+#endif
+// unroll factor of the block-local sweep passes (LDS reads of several controls in flight)
+#ifndef CPMPC_SWEEP_UNROLL
+#define CPMPC_SWEEP_UNROLL 5
 #endif
 #define CPMPC_FUSED_BOUNDS __launch_bounds__(64, (sizeof(R) == 4 ? CPMPC_FUSED_WAVES_F32 : 1))
 
@@ -53,6 +130,7 @@ __device__ unsigned long long g_fused_phase_cycles[8];
 #define CPMPC_TICK_INIT() unsigned long long tick_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tick_last = __builtin_readcyclecounter()
 #define CPMPC_TICK(IDX)                                              \
   do {                                                               \
+    __builtin_amdgcn_sched_barrier(0);                               \
     const unsigned long long tick_now = __builtin_readcyclecounter(); \
     tick_acc[IDX] += tick_now - tick_last;                           \
     tick_last = tick_now;                                            \
@@ -93,8 +171,6 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
   const typename M::Consts& k = SHARED ? a.consts : k_lane;
   const ExtForce<R> fe{R(0), R(0), R(0)};
   const R wu2 = a.wu * a.wu, wd2 = a.wd * a.wd;
-  const int right = (s + 1 < L) ? lane + 1 : lane;
-  const int left = (s > 0) ? lane - 1 : lane;
 
   // ---- per-problem state, replicated in the L lanes of the group -------------------------------------
   int status = a.ist[IS_STATUS * st + p];
@@ -178,9 +254,9 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
     CPMPC_TICK(0);
     // neighbours' boundary controls (u_{k-1} of my first control, u_{k+1} of my last one)
     const R u_first = lds_u[0 * 64 + lane], u_last = lds_u[(SP - 1) * 64 + lane];
-    R u_left = from_lane(u_last, left);
+    R u_left = lane_left(u_last);
     if (s == 0) u_left = u_prev;
-    const R u_right = from_lane(u_first, right);  // unused for s = L-1
+    const R u_right = lane_right(u_first);  // unused for s = L-1
 
     // ================= block-parallel sweeps ===============================================================
     // All three sweeps of the structured QP are linear recurrences in k, so every lane first solves its own
@@ -191,28 +267,40 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
     //     wt_k = Gamma_k - ups_k wt_{k+1},   gwt_k = g_k - ups_k gwt_{k+1}  (wt, gwt = 0 and e = 1 past the block)
     // with Psi_s = diag(w) Phi_{S-2} ... Phi_{s+1} constant inside a block.
 
-    // ---- pivots d_k = diag_k - wd2^2 / d_{k+1} of T = U D U^T: they depend on (lambda, weights) only, so every
-    //      lane runs the whole chain and keeps 1/d of its own block (lane-private LDS) -------------------------
-    bool pd_ok = true;
+    // ---- pivots d_k = diag_k - wd2^2 / d_{k+1} of T = U D U^T ---------------------------------------------------
+    // They depend on (lambda, weights) only.  Scaled by b = wu2 + lambda + 2 wd2 the recurrence is the Moebius map
+    //     delta_k = 1 - gamma / delta_{k+1},   gamma = (wd2 / b)^2 <= 1/4,   delta_{N-1} = (b - wd2) / b
+    // i.e. (p, q)_k = [[1, -gamma], [1, 0]] (p, q)_{k+1} with delta = p / q: a constant 2x2 matrix whose powers
+    // (by squaring; all entries stay <= 1) jump straight to the block boundaries, so no lane walks the whole
+    // horizon: each one starts its own SP pivots from its boundary value inside the sweep-1 pass below.
     R id_right = R(0);  // 1/d of the first control after my block (unused for s = L-1)
     {
-      R idn = R(0);
-#pragma unroll 1
-      for (int sb = L - 1; sb >= 0; --sb) {
-        if (sb == s) id_right = idn;
-#pragma unroll 1
-        for (int i = SP - 1; i >= 0; --i) {
-          const int kk = sb * SP + i;
-          const R nd = (kk < N - 1 ? R(1) : R(0)) + R(1);
-          const R ups = (kk < N - 1) ? (-wd2 * idn) : R(0);
-          const R dk = (wu2 + lam + wd2 * nd) + wd2 * ups;
-          if (!(dk > R(0))) pd_ok = false;
-          idn = Math<R>::rcp(dk);
-          if (sb == s) lds_id[i * 64 + lane] = idn;
+      const R bdiag = wu2 + lam + R(2) * wd2;
+      const R rb = R(1) / bdiag;
+      const R gam = (wd2 * rb) * (wd2 * rb);
+      const Mat2<R> Tm{R(1), -gam, R(1), R(0)};
+      const Mat2<R> Tsp = mat2_pow<R, SP>(Tm);
+      const Mat2<R> Tsp1 = mat2_pow<R, SP - 1>(Tm);
+      // (p, q) at the first control of the last block, then one block further down per step
+      R pq0 = Tsp1.a * ((bdiag - wd2) * rb) + Tsp1.b;
+      R pq1 = Tsp1.c * ((bdiag - wd2) * rb) + Tsp1.d;
+      R myp = R(1), myq = R(0);
+#pragma unroll
+      for (int sb = L - 2; sb >= 0; --sb) {
+        if (sb == s) {
+          myp = pq0;
+          myq = pq1;
         }
+        const R n0 = Tsp.a * pq0 + Tsp.b * pq1;
+        const R n1 = Tsp.c * pq0 + Tsp.d * pq1;
+        pq0 = n0;
+        pq1 = n1;
       }
+      id_right = (myq * rb) / myp;  // 1 / (b delta)
     }
+    bool pd_ok = true;
 
+    CPMPC_TICK(1);
     // ---- sweep 1, local pass down my block ---------------------------------------------------------------
     R Sm[NX][NX], rho[NX], ha[NX];
     R f_part = R(0), cn_part = R(0);
@@ -232,7 +320,7 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
       R u_hi = u_right;
       R u_cur = lds_u[(SP - 1) * 64 + lane];
       R idn = id_right;
-#pragma unroll 1
+#pragma unroll CPMPC_SWEEP_UNROLL
       for (int i = SP - 1; i >= 0; --i) {
         const int kk = s * SP + i;
         const R u_lo = (i > 0) ? lds_u[(i - 1) * 64 + lane] : u_left;
@@ -241,7 +329,10 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
         R g = wu2 * u_cur + wd2 * (u_cur - u_lo);
         if (kk < N - 1) g += wd2 * (u_cur - u_hi);
         const R ups = (kk < N - 1) ? (-wd2 * idn) : R(0);
-        const R idk = lds_id[i * 64 + lane];
+        const R dk = (wu2 + lam + wd2 * ((kk < N - 1 ? R(1) : R(0)) + R(1))) + wd2 * ups;
+        if (!(dk > R(0))) pd_ok = false;
+        const R idk = Math<R>::rcp(dk);
+        lds_id[i * 64 + lane] = idk;
         R Gi[NX];
         unpack<R, NX>(lds_G[i * 64 + lane], Gi);
 #pragma unroll
@@ -267,13 +358,14 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
 #pragma unroll
       for (int t = 0; t < NX; ++t) cn_part += Math<R>::fabs(cdef[t]);
 
+      CPMPC_TICK(2);
       // ---- initial-state residual (node 0) and terminal residual (node S-1), replicated ---------------------
       {
         R x0n[NX], xT[NX];
 #pragma unroll
         for (int t = 0; t < NX; ++t) {
-          x0n[t] = from_lane(xs[t], gbase);
-          xT[t] = from_lane(xe[t], gbase + L - 1);
+          x0n[t] = group_first<R, L>(xs[t], gbase);
+          xT[t] = group_last<R, L>(xe[t], gbase);
           ci[t] = x0n[t] - xm[t];
           e_term[t] = xT[t] - tgt[t];
         }
@@ -296,11 +388,11 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
           R wo = e_blk * w_in[r];
 #pragma unroll
           for (int m = 0; m < NX; ++m) wo += Psi[r][m] * wt[m];
-          const R v = from_lane(wo, right);
+          const R v = lane_right(wo);
           w_in[r] = edge ? w_in[r] : v;
         }
         {
-          const R v = from_lane(gwt + e_blk * gw_in, right);
+          const R v = lane_right(gwt + e_blk * gw_in);
           gw_in = edge ? gw_in : v;
         }
         R T[NX][NX];
@@ -317,7 +409,7 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
         for (int r = 0; r < NX; ++r)
 #pragma unroll
           for (int c = 0; c < NX; ++c) {
-            const R v = from_lane(T[r][c], right);
+            const R v = lane_right(T[r][c]);
             Psi[r][c] = edge ? Psi[r][c] : v;
           }
       }
@@ -370,9 +462,10 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
         }
     }
 
-    CPMPC_TICK(1);
+    CPMPC_TICK(3);
     // ---- group sums, terminal rows ------------------------------------------------------------------------
     R f = group_sum<R, L>(f_part), cn = group_sum<R, L>(cn_part);
+    pd_ok = (group_sum<R, L>(pd_ok ? R(0) : R(1)) == R(0));  // every lane checked the pivots of its own block
     R hv[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
@@ -435,7 +528,6 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
     }
     if (live && status == kTermNone && !pd_ok) status = kTermQpIndefinite;
 
-    CPMPC_TICK(2);
     // ================= sweep 1b, local pass down my block: v_k = -(gw_k + w_k . q) / d_k ====================
     //   w_k . q = psi . wt_k + e_k (w_in . q),  psi = Psi_s^T q,  and  psi . wt_k  obeys wt's recurrence, so W is
     //   never stored.  v_k is parked in lds_du[k]; sweep 2 turns it into du_k in place.
@@ -452,7 +544,7 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
       }
       R om = R(0), e = R(1);
       R idn = id_right;
-#pragma unroll 1
+#pragma unroll CPMPC_SWEEP_UNROLL
       for (int i = SP - 1; i >= 0; --i) {
         const int kk = s * SP + i;
         R Gi[NX];
@@ -469,7 +561,7 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
       }
     }
 
-    CPMPC_TICK(3);
+    CPMPC_TICK(4);
     // ================= sweep 2, up the blocks: du_k = v_k - ups_{k-1} du_{k-1},  dx_{s+1} = Phi dx_s + Gamma du + c ====
     //   local:  dut_k = v_k - ups_{k-1} dut_{k-1},  et_k = -ups_{k-1} et_{k-1}  (dut = 0, et = 1 before the block),
     //           du_k = dut_k + et_k du_in;  ups_{k-1} = -wd2 / d_k uses my own pivots only
@@ -483,7 +575,7 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
         Gt[t] = cdef[t];
         Ht[t] = R(0);
       }
-#pragma unroll 1
+#pragma unroll CPMPC_SWEEP_UNROLL
       for (int i = 0; i < SP; ++i) {
         const int kk = s * SP + i;
         const R upm = (kk > 0) ? (-wd2 * lds_id[i * 64 + lane]) : R(0);
@@ -514,10 +606,10 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
           const bool edge = (s == 0);
 #pragma unroll
           for (int t = 0; t < NX; ++t) {
-            const R v = from_lane(dxe[t], left);
+            const R v = lane_left(dxe[t]);
             dxs[t] = edge ? dxs[t] : v;
           }
-          const R v1 = from_lane(dut + et * du_in, left);
+          const R v1 = lane_left(dut + et * du_in);
           du_in = edge ? du_in : v1;
         }
       }
@@ -526,7 +618,7 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
       R u_lo = u_left;
       R u_cur = lds_u[0 * 64 + lane];
       et = R(1);
-#pragma unroll 1
+#pragma unroll CPMPC_SWEEP_UNROLL
       for (int i = 0; i < SP; ++i) {
         const int kk = s * SP + i;
         const R upm = (kk > 0) ? (-wd2 * lds_id[i * 64 + lane]) : R(0);
@@ -549,7 +641,7 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
     {
       R dxT[NX];
 #pragma unroll
-      for (int t = 0; t < NX; ++t) dxT[t] = from_lane(dxe[t], gbase + L - 1);
+      for (int t = 0; t < NX; ++t) dxT[t] = group_last<R, L>(dxe[t], gbase);
 #pragma unroll
       for (int t = 0; t < NX; ++t) {
         if ((a.term_is_cost >> t) & 1) {
@@ -563,7 +655,7 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
     // du of my left neighbour's last control, for the (u_{k-1} - u_k) row of my first control
     const R du_left = du_in;
 
-    CPMPC_TICK(4);
+    CPMPC_TICK(5);
     // ================= penalty, merit slope ==================================================================
     if (cn > R(0)) {
       const R mu_req = (gd + R(0.5) * curv) / ((R(1) - a.rho) * cn);
@@ -653,7 +745,7 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
       }
     }
 
-    CPMPC_TICK(5);
+    CPMPC_TICK(6);
     // ================= accept / reject, step-length memory, damping, termination ===========================
     if (live && status == kTermNone) {
       a_start = R(1);
@@ -695,7 +787,7 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
     }
   }
 
-  CPMPC_TICK(6);
+  CPMPC_TICK(7);
   // ---- write the iterate (= warm start) and the per-problem solver state back -------------------------------
   if (valid) {
     a.zx[(int64_t)s * st + p] = pack<R, NX>(xs);
