@@ -56,7 +56,7 @@ def cpu_baseline(x0_np, over, seconds_target=15.0):
     from oracle import oracle as orc
     p = orc.default_opt_params(**over)
     cores = os.cpu_count() or 1
-    probe = min(max(512, 8 * cores), x0_np.shape[1])
+    probe = min(max(2048, 32 * cores), x0_np.shape[1])   # large enough that thread start-up does not bias the rate
     t0 = time.perf_counter()
     _, _, _, _, used = orc.step_batch_cold(p, DYN_UI, 0.0, x0_np[:, :probe], num_threads=cores)
     rate = probe / max(time.perf_counter() - t0, 1e-6)
@@ -210,6 +210,16 @@ def main():
                                  "max_abs_du_p99": float(np.quantile(err, 0.99)), "max_abs_du_max": float(err.max()),
                                  "note": "GPU %s vs fp64 oracle on the cpu_baseline sample" % args.dtype}
         line["gpu_over_cpu"] = value / base["value"]
+        # the parity dtype: the same kernels in fp64 on the first lanes of the batch against the fp64 oracle
+        # (north_star's 1e-5 bar on the control sequence; tests/test_gpu_parity.py is the gate, this is the record)
+        n64 = int(min(n, 4096))
+        opt64 = pkg.BatchOptimization(params, max_batch=n64, dtype=torch.float64, device=local_rank)
+        opt64.set_pipeline(args.pipeline)
+        o64 = opt64.step(torch.tensor(x0_np[:, :n64], dtype=torch.float64, device=dev), DYN_UI, 0.0)
+        e64 = np.abs(o64.u.cpu().numpy() - u_cpu[:, :n64]).max(axis=0)
+        line["parity_f64"] = {"lanes": n64, "max_abs_du_max": float(e64.max()), "max_abs_du_median": float(np.median(e64)),
+                              "bar": 1e-5, "note": "GPU fp64 (same kernels, pipeline %s) vs fp64 oracle, same workload"
+                                                   % opt64.pipeline()}
     print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

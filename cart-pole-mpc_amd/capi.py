@@ -77,6 +77,7 @@ class SolverOpts(C.Structure):
         ("lambda_max", C.c_double),
         ("b_x_limit", C.c_double),
         ("u_limit", C.c_double),
+        ("ls_alpha_growth_backtracked", C.c_double),
     ]
 
 

@@ -212,15 +212,15 @@ __device__ __forceinline__ void cartpole_accel(const CartPoleConsts<R>& k, const
     R dDx0 = R(0), dDx1 = R(0), dDx2 = R(0), dDt0 = R(0), dDt1 = R(0), dDt2 = R(0);
     if (on_d) {
       const R inv_n = Math<R>::rcp(n);
-      // d|v|/d(th, v, w)
-      const R dn0 = (vx * (-Lw * c) + vy * (-Lw * s)) * inv_n;
+      // d|v|/d(th, v, w), with  vx + L w s = v  and  c vy - s vx = e  folded in
+      const R dn0 = -(vy * v) * inv_n;
       const R dn1 = vx * inv_n;
-      const R dn2 = (vx * (-k.L * s) + vy * (k.L * c)) * inv_n;
-      dDx0 = k.half_cd * (dn0 * vx + n * (-Lw * c));
+      const R dn2 = (k.L * e) * inv_n;
+      dDx0 = k.half_cd * (dn0 * vx - n * vy);
       dDx1 = k.half_cd * (dn1 * vx + n);
-      dDx2 = k.half_cd * (dn2 * vx + n * (-k.L * s));
-      dDt0 = k.half_cd_L * (dn0 * e + n * (-c * v));
-      dDt1 = k.half_cd_L * (dn1 * e + n * (-s));
+      dDx2 = k.half_cd * (dn2 * vx - n * (k.L * s));
+      dDt0 = k.half_cd_L * (dn0 * e - n * (c * v));
+      dDt1 = k.half_cd_L * (dn1 * e - n * s);
       dDt2 = k.half_cd_L * (dn2 * e + n * k.L);
     }
     const R dFf_dv = k.inv_v_mu * (R(1) - tv * tv) * k.fr;

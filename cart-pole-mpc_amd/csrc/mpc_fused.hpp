@@ -3,24 +3,28 @@
 // The split pipeline (mpc_kernels.hpp) streams the sensitivities Gamma/Phi and the QP factors W/T through
 // HBM between its kernels (measured 6.6 KB per problem and iteration, 40 % of the HBM peak, profiles/).
 // Here lane s of a group of L consecutive lanes owns shooting interval s of one problem for the whole
-// solve: its node x_s and Phi_s live in registers, its SP controls, the step and Gamma_s in lane-private LDS,
-// the tridiagonal factors in registers; nothing of it reaches memory.  Per iteration:
+// solve: its node x_s, Phi_s and defect live in registers; its SP controls, the step, Gamma_s and the
+// per-control QP factors {1/d_k, (U^-1 g)_k} in lane-private LDS (80 scalars per lane = 20 KB per wave, so 8
+// waves per CU = 2 per SIMD, which is also what the ~185 VGPRs allow); nothing of it reaches memory.
+// Per iteration:
 //   linearise      every lane integrates its own interval (RK4 + forward sensitivities), in parallel
-//   sweep 1        T = U D U^T and W = U^-1 R^T run DOWN the intervals: lane s works in turn s and hands
-//                  {Psi, w_{k+1}, gw_{k+1}, d_{k+1}} to lane s-1 through wave shuffles; S, rho, the free
-//                  response, f and |c|_1 are per-lane partial sums, reduced over the group afterwards
-//   NX x NX LDL^T  every lane of the group solves the same small system (bitwise identical inputs)
-//   sweep 1b       with q known, W q is a scalar recurrence  omega_k = psi . Gamma_k - ups_k omega_{k+1},
-//                  psi = Psi^T q, again DOWN the intervals (W itself is never stored)
-//   sweep 2        U^T du = D^-1 y and the state recovery run UP the intervals the same way
+//   QP sweeps      T = U D U^T, W = U^-1 R^T, gw = U^-1 g (down the horizon), then U^-T and the state recovery
+//                  (up) are linear recurrences in k.  Every lane solves its own block in block-local
+//                  coordinates (carry-in = 0) plus the scalar chain that says how a carry-in propagates; a
+//                  chain of L-1 steps over the lanes (DPP row shifts) fixes the true block-boundary values
+//                  {Psi_s, w_in, gw_in} / {dx_s, du_in}; each lane then corrects its block locally.  The
+//                  pivots d_k depend on (lambda, weights) only: a Moebius recurrence whose block-boundary
+//                  values come from powers of one 2x2 matrix, so no lane walks the whole horizon.
+//   NX x NX LDL^T  every lane of the group solves the same small system (bitwise identical inputs: group
+//                  sums are commutative butterflies over quad permutes)
 //   line search    every lane rolls out its own interval of the trial point; the merit is a group sum
 // 64/L problems share a wave, so the lock-step line search pays the maximum trial count over 16 (L = 4)
-// problems instead of 64.  Only the sequential sweeps leave lanes idle (about a fifth of the instructions).
-// prepare_kernel / finalize_kernel of mpc_kernels.hpp run before / after, unchanged: the workspace fields
-// zx, zu (iterate = warm start), sc and ist are this kernel's only global traffic.
+// problems instead of 64.  prepare_kernel / finalize_kernel of mpc_kernels.hpp run before / after,
+// unchanged: the workspace fields zx, zu (iterate = warm start), sc and ist are this kernel's only global
+// traffic.
 //
-// The arithmetic is the split pipeline's, operation for operation; group sums use a butterfly whose
-// result is bitwise identical in every lane of the group.
+// Same algorithm as the split pipeline (same QP, same line search, same decisions); the sweeps associate
+// their sums differently, so results agree to rounding (fp64: 1e-9), not bitwise.
 #pragma once
 #include "mpc_kernels.hpp"
 
@@ -750,7 +754,7 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
     if (live && status == kTermNone) {
       a_start = R(1);
       if (accepted && a.alpha_growth > R(0)) {
-        a_start = a.alpha_growth * alpha;
+        a_start = (evals > 1 ? a.alpha_growth_bt : a.alpha_growth) * alpha;
         if (!(a_start < R(1))) a_start = R(1);
       }
       if (accepted) {

@@ -120,7 +120,7 @@ struct SolverArgs {
   int term_is_cost;    // bit t set: terminal row t is a cost (weight >= 0), else an equality
   // solver options
   int max_ls;
-  R c1, shrink_max, shrink_min, alpha_growth, rho;
+  R c1, shrink_max, shrink_min, alpha_growth, alpha_growth_bt, rho;
   R lam_init, lam_fail_init, lam_up, lam_down, lam_min, lam_max;
   R bx_lim, u_lim;
   R rel_tol, fo_tol, mu_init;
@@ -757,7 +757,7 @@ __global__ CPMPC_QPLS_BOUNDS void qp_ls_kernel(const SolverArgs<R, M> a) {
   if (status == kTermNone) {
     a_start = R(1);
     if (accepted && a.alpha_growth > R(0)) {
-      a_start = a.alpha_growth * alpha;
+      a_start = (evals > 1 ? a.alpha_growth_bt : a.alpha_growth) * alpha;
       if (!(a_start < R(1))) a_start = R(1);
     }
     if (accepted) {

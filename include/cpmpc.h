@@ -94,6 +94,7 @@ typedef struct cpmpc_solver_opts {
   double lambda_max;
   double b_x_limit;
   double u_limit;
+  double ls_alpha_growth_backtracked; /* growth used instead of ls_alpha_growth when the accepted search backtracked */
 } cpmpc_solver_opts;
 
 void cpmpc_default_params(cpmpc_params* p);           /* optimization.hpp:12-48 defaults */

@@ -60,6 +60,7 @@ void orc_default_solver_opts(orc_solver_opts* o) {
   o->lambda_max = 1.0e6;
   o->b_x_limit = 5.0;
   o->u_limit = 300.0;
+  o->ls_alpha_growth_backtracked = 2.0;
 }
 
 /* ------------------------------------------------------------------------------------------- */
@@ -835,9 +836,10 @@ static int solve(const orc_model* m, const orc_opt_params* p, const orc_solver_o
      * quadratic through phi(0), phi'(0), phi(alpha), safeguarded to [ls_shrink_min, ls_shrink_max]
      * times the current step */
     double alpha = alpha_start;
-    int accepted = 0;
+    int accepted = 0, backtracked = 0;
     double phi_t = 0.0, f_t = 0.0, cn_t = 0.0;
     for (int t = 0; t < o->max_line_search_iterations; ++t) {
+      backtracked = (t > 0);
       retract(m, p, o, z, dz, alpha, zt);
       problem_eval(m, p, dyn, x_current, set_point, u_prev, zt, rt, ct, NULL, NULL);
       ++ls_evals;
@@ -861,7 +863,7 @@ static int solve(const orc_model* m, const orc_opt_params* p, const orc_solver_o
      * a different one) it starts from the full step again; 0 disables (always start from 1) */
     alpha_start = 1.0;
     if (accepted && o->ls_alpha_growth > 0.0) {
-      alpha_start = o->ls_alpha_growth * alpha;
+      alpha_start = (backtracked ? o->ls_alpha_growth_backtracked : o->ls_alpha_growth) * alpha;
       if (!(alpha_start < 1.0)) alpha_start = 1.0;
     }
     if (accepted) {

@@ -234,6 +234,29 @@ def test_step_parity_configurations(pkg, orc, over):
     assert (err[good] < 1e-5).mean() >= 0.99, np.sort(err[good])[-5:]
 
 
+@pytest.mark.parametrize("pipeline", ["fused", "split"])
+@pytest.mark.parametrize("sopts", [
+    dict(ls_alpha_growth=2.0, ls_alpha_growth_backtracked=1.0),   # grow the step only after a first-trial accept
+    dict(ls_alpha_growth=0.0),                                    # no step-length memory
+    dict(ls_shrink_max=0.7, ls_shrink_min=0.2, armijo_c1=1e-2, max_line_search_iterations=3,
+         lambda_failure_init=1.0, penalty_rho=0.5),
+])
+def test_step_parity_solver_options(pkg, orc, sopts, pipeline):
+    """The knobs of this repo's SQP specification (cpmpc_solver_opts) mean the same in the
+    kernels and in the oracle."""
+    rng = np.random.default_rng(7)
+    x0 = random_states(rng, 512)
+    opt = pkg.BatchOptimization(pkg.default_params(**NO_TOL), max_batch=512, dtype=torch.float64, device=0,
+                                opts=pkg.capi.default_solver_opts(**sopts))
+    opt.set_pipeline(pipeline)
+    out = opt.step(T(x0), DYN_UI, 0.0, want_stats=True)
+    u_cpu, _, st_cpu, it_cpu, _ = orc.step_batch_cold(orc.default_opt_params(**NO_TOL), DYN_UI, 0.0, x0,
+                                                      opts=orc.default_solver_opts(**sopts))
+    assert (N_(out.status) == st_cpu).all() and (N_(out.iterations) == it_cpu).all()
+    err = np.abs(N_(out.u) - u_cpu).max(axis=0)
+    assert err.max() < 1e-5, np.sort(err)[-5:]
+
+
 def test_edge_batches(pkg, orc):
     """B = 1, a ragged B, capacity errors, and the reference's scratch.py call sequence at B = 1."""
     rng = np.random.default_rng(3)
