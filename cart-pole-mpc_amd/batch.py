@@ -62,6 +62,32 @@ class BatchOutputs:
             lines.append("  max |c|_1: %.3e" % self.final_eq_l1.abs().max().item())
         return "\n".join(lines)
 
+    def lane_json(self, lane, initial_state, previous_solution=None):
+        """One problem of the batch in the JSON log format of OptimizationOutputs (optimization/wasm.cc:46-65,
+        toJson :104-105): keys sorted, compact, as nlohmann::json::dump() prints them.  `initial_state` is the
+        [4, B] tensor passed to step(); `previous_solution` the [dim, B] tensor of get_solution() (optional).
+        solver_outputs carries this repo's fields (mini_opt's serialisation is not available)."""
+        import json
+
+        def col(t):
+            return [float(v) for v in t[..., lane].double().cpu().reshape(-1)]
+
+        names = ("b_x", "th_1", "b_x_dot", "th_1_dot")
+        pred = self.predicted_states[:, :, lane].double().cpu().tolist()
+        obj = {
+            "initial_state": dict(zip(names, col(initial_state))),
+            "previous_solution": col(previous_solution) if previous_solution is not None else [],
+            "solver_outputs": {
+                "termination_state": capi.TERM_NAMES[int(self.status[lane])],
+                "iterations": int(self.iterations[lane]) if self.iterations is not None else 0,
+                "final_cost": float(self.final_cost[lane]) if self.final_cost is not None else 0.0,
+                "final_equality_l1": float(self.final_eq_l1[lane]) if self.final_eq_l1 is not None else 0.0,
+            },
+            "u": col(self.u),
+            "predicted_states": [dict(zip(names, row)) for row in pred],
+        }
+        return json.dumps(obj, sort_keys=True, separators=(",", ":"))
+
 
 class BatchOptimization:
     """B independent pendulum::Optimization controllers solved in lock-step on one GPU."""

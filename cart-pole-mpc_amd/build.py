@@ -64,8 +64,8 @@ def build_host(force=False, verbose=False):
     import sysconfig
 
     build_lib()
-    srcs = [os.path.join(HOST, f) for f in ("optimization.cc", "simulator.cc")]
-    hdrs = [os.path.join(HOST, f) for f in ("optimization.hpp", "simulator.hpp", "structs.hpp")]
+    srcs = [os.path.join(HOST, f) for f in ("optimization.cc", "simulator.cc", "json.cc")]
+    hdrs = [os.path.join(HOST, f) for f in ("optimization.hpp", "simulator.hpp", "structs.hpp", "json.hpp")]
     cxx = os.environ.get("CXX", "g++")
     common = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-Wextra"]
     link = ["-L" + LIB_DIR, "-lcpmpc", "-Wl,-rpath,$ORIGIN"]

@@ -1,10 +1,13 @@
 // pypendulum.cc -- Python module `pypendulum` with the names of the reference's nanobind wrapper
 // (wrapper/wrapper.cc:40-98), bound with pybind11 over the C++ facade (nanobind is not available
 // in this image).  Additions, all batched: Optimization(params, max_batch), .step_batch(),
-// .reset(); Simulator.set_state().
+// .reset(); Simulator.set_state(); and the JSON wire format of the reference's browser build (wasm.cc:19-65):
+// X.to_json() / X.from_json(text) on every struct, OptimizationOutputs.{get_log, window_length, get_control,
+// get_predicted_state} with the names of wasm.cc:86-105 in snake_case.
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
+#include "json.hpp"
 #include "optimization.hpp"
 #include "simulator.hpp"
 
@@ -27,7 +30,9 @@ PYBIND11_MODULE(pypendulum, m) {
       .def_readwrite("v_mu_b", &SingleCartPoleParams::v_mu_b)
       .def_readwrite("c_d_1", &SingleCartPoleParams::c_d_1)
       .def_readwrite("x_s", &SingleCartPoleParams::x_s)
-      .def_readwrite("k_s", &SingleCartPoleParams::k_s);
+      .def_readwrite("k_s", &SingleCartPoleParams::k_s)
+      .def("to_json", [](const SingleCartPoleParams& self) { return ToJson(self); })
+      .def_static("from_json", &ParamsFromJson);
 
   py::class_<OptimizationParams>(m, "OptimizationParams")
       .def(py::init<>())
@@ -44,24 +49,43 @@ PYBIND11_MODULE(pypendulum, m) {
       .def_readwrite("b_x_final_cost_weight", &OptimizationParams::b_x_final_cost_weight)
       .def_readwrite("th_final_cost_weight", &OptimizationParams::th_final_cost_weight)
       .def_readwrite("b_x_dot_final_cost_weight", &OptimizationParams::b_x_dot_final_cost_weight)
-      .def_readwrite("th_dot_final_cost_weight", &OptimizationParams::th_dot_final_cost_weight);
+      .def_readwrite("th_dot_final_cost_weight", &OptimizationParams::th_dot_final_cost_weight)
+      .def("to_json", [](const OptimizationParams& self) { return ToJson(self); })
+      .def_static("from_json", &OptimizationParamsFromJson);
 
   py::class_<SingleCartPoleState>(m, "SingleCartPoleState")
       .def(py::init<double, double, double, double>())
       .def_readwrite("b_x", &SingleCartPoleState::b_x)
       .def_readwrite("th_1", &SingleCartPoleState::th_1)
       .def_readwrite("b_x_dot", &SingleCartPoleState::b_x_dot)
-      .def_readwrite("th_1_dot", &SingleCartPoleState::th_1_dot);
+      .def_readwrite("th_1_dot", &SingleCartPoleState::th_1_dot)
+      .def("to_json", [](const SingleCartPoleState& self) { return ToJson(self); })
+      .def_static("from_json", &StateFromJson);
 
   py::class_<OptimizationOutputs>(m, "OptimizationOutputs")
       .def("solver_summary", [](const OptimizationOutputs& self) { return self.solver_outputs.ToString(); })
+      .def("get_log", [](const OptimizationOutputs& self) { return self.solver_outputs.ToString(); })  // wasm.cc:88-89
+      .def("window_length", [](const OptimizationOutputs& self) { return self.u.size(); })              // wasm.cc:90-91
+      .def("get_control",
+           [](const OptimizationOutputs& self, std::size_t index) {                                     // wasm.cc:92-97
+             if (index >= self.u.size()) throw py::index_error("control index out of range");
+             return self.u[index];
+           })
+      .def("get_predicted_state",
+           [](const OptimizationOutputs& self, std::size_t index) {                                     // wasm.cc:98-103
+             if (index >= self.predicted_states.size()) throw py::index_error("state index out of range");
+             return self.predicted_states[index];
+           })
+      .def_readonly("initial_state", &OptimizationOutputs::initial_state)
       .def_property_readonly("termination_state",
                              [](const OptimizationOutputs& self) {
                                return static_cast<int>(self.solver_outputs.termination_state);
                              })
       .def_readonly("previous_solution", &OptimizationOutputs::previous_solution)
       .def_readonly("u", &OptimizationOutputs::u)
-      .def_readonly("predicted_states", &OptimizationOutputs::predicted_states);
+      .def_readonly("predicted_states", &OptimizationOutputs::predicted_states)
+      .def("to_json", [](const OptimizationOutputs& self) { return ToJson(self); })  // wasm.cc:104-105
+      .def_static("from_json", &OptimizationOutputsFromJson);
 
   py::class_<BatchOptimizationOutputs>(m, "BatchOptimizationOutputs")
       .def_readonly("batch", &BatchOptimizationOutputs::batch)
@@ -81,7 +105,14 @@ PYBIND11_MODULE(pypendulum, m) {
       .def("reset", &Optimization::Reset)
       .def("set_previous_solution", &Optimization::SetPreviousSolution);
 
-  py::class_<Vector2>(m, "Vector2").def(py::init<double, double>());
+  py::class_<Vector2>(m, "Vector2")
+      .def(py::init<double, double>())
+      .def_readwrite("x", &Vector2::x)
+      .def_readwrite("y", &Vector2::y)
+      .def("to_json", [](const Vector2& self) { return ToJson(self); })
+      .def_static("from_json", &Vector2FromJson)
+      .def_static("list_from_json", &Vector2ListFromJson);
+  m.def("get_default_optimization_params", []() { return OptimizationParams{}; });  // wasm.cc:118-119
 
   py::class_<Simulator>(m, "Simulator")
       .def(py::init<>())

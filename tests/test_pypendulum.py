@@ -70,6 +70,48 @@ def test_no_gpu_is_a_loud_error(pp, pkg):
         pp.Simulator().step(pp.SingleCartPoleParams(*DYN_TEST), 0.01, 0.0, pp.Vector2(0, 0), pp.Vector2(0, 0))
 
 
+def test_json_wire_format_of_the_structs(pp):
+    """wasm.cc:19-28: every struct as a JSON object keyed by its field names; text as nlohmann::json::dump()
+    prints it (keys sorted, no whitespace, integers as integers, shortest round-trip doubles with '.0' on
+    integral values) -- for these magnitudes the same text as Python's compact sorted dump."""
+    import json
+    canon = lambda t: json.dumps(json.loads(t), sort_keys=True, separators=(",", ":"))
+    p = pp.get_default_optimization_params()           # wasm.cc:118-119 getDefaultOptimizationParams
+    t = p.to_json()
+    assert t == canon(t)
+    assert json.loads(t) == dict(
+        control_dt=0.01, window_length=40, state_spacing=10, max_iterations=8, relative_exit_tol=1e-5,
+        absolute_first_derivative_tol=1e-6, equality_penalty_initial=1.0, u_guess_sinusoid_amplitude=10.0,
+        u_cost_weight=0.1, u_derivative_cost_weight=0.1, b_x_final_cost_weight=150.0, th_final_cost_weight=-1.0,
+        b_x_dot_final_cost_weight=-1.0, th_dot_final_cost_weight=-1.0)       # optimization.hpp:12-48 defaults
+    assert '"window_length":40,' not in t and t.endswith('"window_length":40}')   # integers stay integers
+    q = pp.OptimizationParams.from_json(json.dumps(json.loads(t), indent=2))         # any standard spelling parses
+    assert q.to_json() == t
+    d = pp.SingleCartPoleParams(*DYN_TEST)
+    assert json.loads(d.to_json()) == dict(zip("m_b m_1 l_1 g mu_b v_mu_b c_d_1 x_s k_s".split(), DYN_TEST))
+    assert pp.SingleCartPoleParams.from_json(d.to_json()).to_json() == d.to_json() == canon(d.to_json())
+    rng = np.random.default_rng(5)
+    for _ in range(300):
+        v = (rng.standard_normal(4) * 10.0 ** rng.integers(-12, 13, 4)).tolist()
+        v[rng.integers(0, 4)] = float(rng.integers(-1000, 1000))              # integral values print as 'd.0'
+        st = pp.SingleCartPoleState(*v)
+        t = st.to_json()
+        assert t == canon(t), t
+        back = pp.SingleCartPoleState.from_json(t)
+        assert [back.b_x, back.th_1, back.b_x_dot, back.th_1_dot] == v         # shortest digits round-trip exactly
+    assert set(json.loads(pp.SingleCartPoleState(0, 0, 0, 0).to_json())) == {"b_x", "th_1", "th_1_dot", "b_x_dot"}
+    # layout edges of the number format: fixed for 1e-4 <= |v| < 1e15, exponent form outside, non-finite -> null
+    edge = pp.SingleCartPoleState(1e-4, 99999e-9, 123456789012345.0, 1e15).to_json()
+    assert edge == '{"b_x":0.0001,"b_x_dot":123456789012345.0,"th_1":9.9999e-05,"th_1_dot":1e+15}'
+    assert pp.SingleCartPoleState(float("nan"), -0.0, float("inf"), 5e-324).to_json() == \
+        '{"b_x":null,"b_x_dot":null,"th_1":-0.0,"th_1_dot":5e-324}'
+    f = pp.Vector2.list_from_json('[{"x": 1, "y": 2.5}, {"y": -3e2, "x": 0}]')   # the f_external argument, wasm.cc:78-80
+    assert [(a.x, a.y) for a in f] == [(1.0, 2.5), (0.0, -300.0)]
+    for bad in ('{"b_x":1}', '{"b_x":1,"th_1":2,"b_x_dot":"3","th_1_dot":4}', '{"b_x":1,', "[1,2]", ""):
+        with pytest.raises(ValueError):
+            pp.SingleCartPoleState.from_json(bad)
+
+
 @pytest.mark.gpu
 def test_scratch_py_call_sequence(pp, orc):
     """model/scratch.py:22-40 verbatim, then compared with the oracle (BASELINE config 1 plumbing,
@@ -103,6 +145,41 @@ def test_scratch_py_call_sequence(pp, orc):
         np.testing.assert_allclose(outputs.u, o.u, rtol=0, atol=1e-5)
         np.testing.assert_allclose([[s.b_x, s.th_1, s.b_x_dot, s.th_1_dot] for s in outputs.predicted_states],
                                    o.predicted_states, rtol=0, atol=1e-5)
+        # wasm.cc:46-65,86-105: the log of a step as JSON and the accessor names of the browser build
+        import json
+        text = outputs.to_json()
+        j = json.loads(text)
+        assert text == json.dumps(j, sort_keys=True, separators=(",", ":"))
+        assert list(j) == ["initial_state", "predicted_states", "previous_solution", "solver_outputs", "u"]
+        assert j["u"] == list(outputs.u) and j["previous_solution"] == list(outputs.previous_solution)
+        assert len(j["predicted_states"]) == N and j["predicted_states"][3]["th_1"] == outputs.predicted_states[3].th_1
+        assert j["initial_state"] == dict(b_x=0.0, th_1=0.0, b_x_dot=0.0, th_1_dot=0.0)
+        assert j["solver_outputs"]["termination_state"] in outputs.solver_summary()
+        back = pp.OptimizationOutputs.from_json(text)
+        assert back.to_json() == text and back.termination_state == outputs.termination_state
+        assert outputs.window_length() == N and outputs.get_control(1) == outputs.u[1]
+        assert outputs.get_predicted_state(N - 1).b_x == outputs.predicted_states[N - 1].b_x
+        assert outputs.get_log() == outputs.solver_summary()
+        with pytest.raises(IndexError):
+            outputs.get_control(N)
+        # the batched API writes the same log for a lane
+        import importlib
+        import torch
+        pkg = importlib.import_module("cart-pole-mpc_amd")
+        bo = pkg.BatchOptimization(pkg.default_params(
+            max_iterations=30, state_spacing=10, window_length=N, absolute_first_derivative_tol=1e-3,
+            u_cost_weight=0.0, b_x_final_cost_weight=5.0, b_x_dot_final_cost_weight=100.0,
+            th_dot_final_cost_weight=100.0), max_batch=3, dtype=torch.float64, device=0)
+        x0b = torch.zeros(4, 3, dtype=torch.float64, device="cuda:0")
+        bout = bo.step(x0b, [1.0, 0.1, 0.25, 9.81, 0.05, 0.1, 0.02, 0.8, 100.0], 0.0, want_stats=True)
+        jb = json.loads(bout.lane_json(2, x0b, bo.get_solution(3)))
+        assert list(jb) == list(j) and jb["solver_outputs"]["termination_state"] == j["solver_outputs"]["termination_state"]
+        np.testing.assert_allclose(jb["u"], j["u"], rtol=0, atol=1e-9)
+        # previous_solution is the solution of the step BEFORE (optimization.cc:84-85): empty on the first one
+        assert j["previous_solution"] == []
+        second = json.loads(opt.step(x0_initial, params, 0.0).to_json())
+        np.testing.assert_allclose(second["previous_solution"], jb["previous_solution"], rtol=0, atol=1e-9)
+        assert jb["predicted_states"][N - 1].keys() == j["predicted_states"][N - 1].keys()
 
 
 @pytest.mark.gpu
