@@ -92,7 +92,11 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # CPMPC_BENCH_FORCE_DIST=1: run the RCCL path (process group, gather, barrier, max-reduce) in a world of one
+    force_dist = os.environ.get("CPMPC_BENCH_FORCE_DIST", "0") == "1"
+    if world > 1 or force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     pkg = importlib.import_module("cart-pole-mpc_amd")
@@ -109,24 +113,28 @@ def main():
     opt.set_pipeline(args.pipeline)
     outs = [pkg.BatchOutputs(), pkg.BatchOutputs()]
     gather = None
-    if world > 1 and not args.no_gather:
-        gather = sharding.ResultGather(N, B, tdt, dev, dst=0, depth=2)
+    if (world > 1 or force_dist) and not args.no_gather:
+        gather = sharding.ResultGather(N, B, tdt, dev, dst=0, depth=2, force=force_dist)
 
-    def one_step(i):
-        slot = i % 2
+    state = {"n": 0, "slot": 0}
+
+    def one_step(_):
+        slot = state["n"] % 2        # output buffers and gather slots advance together, warm-up included
+        state["n"] += 1
         if gather is not None:
             gather.wait_slot(slot)   # the buffer we are about to overwrite has been sent
         opt.reset()                  # cold start: every step is a full re-plan from the sinusoid guess
         o = opt.step(x0, DYN_UI, 0.0, want_predicted=True, want_stats=True, out=outs[slot])
         if gather is not None:
-            gather.submit(o.u)
+            assert gather.submit(o.u) == slot
+        state["slot"] = slot
         return o
 
     def fence():
         if gather is not None:
             gather.finish()
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
@@ -145,8 +153,7 @@ def main():
     opt.profile_enable(False)
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     total_problems = world * B
@@ -220,9 +227,18 @@ def main():
         line["parity_f64"] = {"lanes": n64, "max_abs_du_max": float(e64.max()), "max_abs_du_median": float(np.median(e64)),
                               "bar": 1e-5, "note": "GPU fp64 (same kernels, pipeline %s) vs fp64 oracle, same workload"
                                                    % opt64.pipeline()}
-    print(json.dumps(line))
-    if world > 1:
+    if gather is not None:
+        # what rank 0 holds after the last step: the control sequences of all ranks, in global problem order
+        full = gather.assembled(state["slot"])
+        line["gathered"] = {"shape": list(full.shape), "own_block_intact": bool(torch.equal(full[:, :B], out.u))}
+    if dist.is_initialized():
         dist.destroy_process_group()
+    # RCCL writes a version banner through C stdio, which is flushed at exit: flush it now so that the JSON line
+    # is the last line on stdout
+    import ctypes
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
+    print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -23,14 +23,16 @@ class ResultGather:
     """Gathers equally sized [N, B_local] result blocks to `dst`, double-buffered so that the
     gather of step i overlaps the solve of step i+1 (the collective runs on RCCL's stream)."""
 
-    def __init__(self, n_rows, b_local, dtype, device, dst=0, depth=2):
+    def __init__(self, n_rows, b_local, dtype, device, dst=0, depth=2, force=False):
+        """force=True runs the collective even in a world of one (exercises the backend on a single GPU)."""
         self.dst = dst
         self.depth = depth
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.active = dist.is_initialized() and (self.world > 1 or force)
         self.pending = [None] * depth
         self.recv = None
-        if self.world > 1 and self.rank == dst:
+        if self.active and self.rank == dst:
             self.recv = [[torch.empty((n_rows, b_local), dtype=dtype, device=device) for _ in range(self.world)]
                          for _ in range(depth)]
         self.i = 0
@@ -48,7 +50,7 @@ class ResultGather:
         """Start gathering `block` (this rank's results for the current step)."""
         slot = self.slot()
         self.wait_slot(slot)
-        if self.world > 1:
+        if self.active:
             self.pending[slot] = dist.gather(block, self.recv[slot] if self.rank == self.dst else None,
                                              dst=self.dst, async_op=True)
         self.i += 1
