@@ -505,19 +505,23 @@ static void launch_linearize(const SolverArgs<R, M>& a, int SP, const XV<R, M::N
 #undef CPMPC_LIN
 }
 
-// fused pipeline: built for the single pendulum and these (L = S-1, SP) pairs
+// fused pipeline: built for both models and these (L = S-1, SP) pairs
 static bool fused_built(int model, int L, int SP) {
-  if (model != CPMPC_MODEL_SINGLE) return false;
+  (void)model;
   return (L == 4 && SP == 10) || (L == 8 && SP == 5) || (L == 2 && SP == 10) || (L == 4 && SP == 5);
 }
 static bool use_fused(const cpmpc_solver* s) {
   if (s->pipeline == CPMPC_PIPELINE_SPLIT) return false;
-  return fused_built(s->model, s->S - 1, s->SP);
+  if (!fused_built(s->model, s->S - 1, s->SP)) return false;
+  // AUTO: the 6-state model in fp64 needs 61 KB of LDS per wave in the fused kernel (2 waves per CU); the split
+  // pipeline is as fast there (measured 10.1 vs 9.7 M re-plans/s), so it stays the default for that case
+  if (s->pipeline == CPMPC_PIPELINE_AUTO && s->model == CPMPC_MODEL_DOUBLE && s->dtype == CPMPC_F64) return false;
+  return true;
 }
 
 template <typename R, typename M>
 static void launch_fused(const SolverArgs<R, M>& a, int L, int SP, int max_iters, hipStream_t stream) {
-  if constexpr (M::NX == 4) {
+  {
     const int ppw = 64 / L;
     const dim3 grid((unsigned)((a.B + ppw - 1) / ppw));
 #define CPMPC_FUSED(LV, SPV)                                                                                \

@@ -125,7 +125,7 @@ __device__ __forceinline__ R group_last(R v, int gbase) {
 #ifndef CPMPC_SWEEP_UNROLL
 #define CPMPC_SWEEP_UNROLL 5
 #endif
-#define CPMPC_FUSED_BOUNDS __launch_bounds__(64, (sizeof(R) == 4 ? CPMPC_FUSED_WAVES_F32 : 1))
+#define CPMPC_FUSED_BOUNDS __launch_bounds__(64, ((sizeof(R) == 4 && M::NX <= 4) ? CPMPC_FUSED_WAVES_F32 : 1))
 
 // Debug build only (-DCPMPC_FUSED_TIMING): shader-clock cycles per phase, summed over waves, read back by
 // cpmpc_debug_phase_cycles().  Not part of the product library.

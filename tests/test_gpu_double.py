@@ -86,9 +86,11 @@ def test_double_linearize_matches_oracle(pkg, orc, N, sp):
             np.testing.assert_allclose(Gam[s * sp:(s + 1) * sp, :, b].T, J[:, 12:], rtol=0, atol=1e-10)
 
 
-def _step_vs_oracle(pkg, orc, over, x0, set_point):
+def _step_vs_oracle(pkg, orc, over, x0, set_point, pipeline="auto"):
     B = x0.shape[1]
     opt = pkg.BatchOptimization(pkg.default_params(**over), max_batch=B, dtype=torch.float64, device=0, model="double")
+    opt.set_pipeline(pipeline)
+    assert pipeline == "auto" or opt.pipeline() == pipeline
     out = opt.step(T(x0), DYN, set_point)
     u_cpu, pred_cpu, st_cpu, it_cpu, _ = orc.step_batch_cold(orc.default_opt_params(**over), DYN, set_point, x0,
                                                              want_pred=True, model="double")
@@ -99,13 +101,14 @@ def _step_vs_oracle(pkg, orc, over, x0, set_point):
     return out, ok, err, perr
 
 
-def test_double_step_parity_fixed_iterations(pkg, orc):
+@pytest.mark.parametrize("pipeline", ["split", "fused"])
+def test_double_step_parity_fixed_iterations(pkg, orc, pipeline):
     """5 SQP iterations, exits disabled, states up to 0.15 rad from upright (most of these do not converge
     within the 0.4 s horizon): every lane within 1e-5 of the oracle on u (fp64)."""
     rng = np.random.default_rng(5)
     x0 = near_upright(rng, 320)
     over = dict(OVER, max_iterations=5, relative_exit_tol=0.0, absolute_first_derivative_tol=0.0)
-    out, ok, err, perr = _step_vs_oracle(pkg, orc, over, x0, 0.05)
+    out, ok, err, perr = _step_vs_oracle(pkg, orc, over, x0, 0.05, pipeline)
     assert ok.all()
     assert err.max() < 1e-5 and perr.max() < 1e-5
 
@@ -113,8 +116,9 @@ def test_double_step_parity_fixed_iterations(pkg, orc):
 SOFT = dict(state_spacing=5, th_final_cost_weight=200.0, th_dot_final_cost_weight=20.0, b_x_dot_final_cost_weight=20.0)
 
 
+@pytest.mark.parametrize("pipeline", ["split", "fused"])
 @pytest.mark.parametrize("over,min_conv", [(dict(max_iterations=10), 0.15), (dict(max_iterations=10, **SOFT), 0.95)])
-def test_double_step_parity_with_exits(pkg, orc, over, min_conv):
+def test_double_step_parity_with_exits(pkg, orc, over, min_conv, pipeline):
     """Exits enabled: same termination state and iteration count, controls within 1e-5 on every lane.
     With the default hard terminal equalities only part of the batch converges inside 10 iterations; with
     soft terminal weights (the configuration that balances robustly) nearly all of it does."""
@@ -123,7 +127,7 @@ def test_double_step_parity_with_exits(pkg, orc, over, min_conv):
     x0 = near_upright(rng, B, 0.05)
     x0[0] *= 0.2
     x0[3:] *= 0.2
-    out, ok, err, perr = _step_vs_oracle(pkg, orc, dict(OVER, **over), x0, 0.02)
+    out, ok, err, perr = _step_vs_oracle(pkg, orc, dict(OVER, **over), x0, 0.02, pipeline)
     assert ok.mean() > 0.98
     assert (N_(out.final_eq_l1) < 1e-4).mean() >= min_conv
     assert err[ok].max() < 1e-5 and perr[ok].max() < 1e-5

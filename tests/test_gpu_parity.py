@@ -544,4 +544,8 @@ def test_pipeline_selection(pkg):
         opt2.set_pipeline("fused")
     assert ei.value.code == pkg.capi.ERR_UNSUPPORTED
     opt3 = pkg.BatchOptimization(pkg.default_params(), max_batch=64, dtype=torch.float32, device=0, model="double")
-    assert opt3.pipeline() == "split"
+    assert opt3.pipeline() == "fused"                  # both models are built; fp64 double defaults to split (LDS)
+    opt4 = pkg.BatchOptimization(pkg.default_params(), max_batch=64, dtype=torch.float64, device=0, model="double")
+    assert opt4.pipeline() == "split"
+    opt4.set_pipeline("fused")
+    assert opt4.pipeline() == "fused"
