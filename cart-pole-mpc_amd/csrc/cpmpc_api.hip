@@ -192,9 +192,12 @@ struct cpmpc_solver {
   int pipeline = CPMPC_PIPELINE_AUTO;
 };
 
+// 2: a register-resident linearisation is compiled for this spacing; 1: served by the generic kernel
+// (run-time spacing, O(spacing^2) workspace traffic per interval); 0: not a spacing
 extern "C" int cpmpc_supported_state_spacing(int spacing) {
-  return spacing == 1 || spacing == 2 || spacing == 4 || spacing == 5 || spacing == 8 || spacing == 10 ||
-         spacing == 20;
+  if (spacing < 1) return 0;
+  return (spacing == 1 || spacing == 2 || spacing == 4 || spacing == 5 || spacing == 8 || spacing == 10 ||
+          spacing == 20) ? 2 : 1;
 }
 
 static int validate_params(const cpmpc_params* p) {
@@ -210,10 +213,6 @@ static int validate_params(const cpmpc_params* p) {
   if (!(p->u_derivative_cost_weight >= 0.0))
     return fail(CPMPC_ERR_INVALID_ARG, "u_derivative_cost_weight must be >= 0 (optimization.cc:21)");
   if (p->window_length > 4096) return fail(CPMPC_ERR_UNSUPPORTED, "window_length > 4096 is not supported");
-  if (!cpmpc_supported_state_spacing((int)p->state_spacing))
-    return fail(CPMPC_ERR_UNSUPPORTED,
-                "state_spacing %llu has no compiled kernel (built: 1,2,4,5,8,10,20)",
-                (unsigned long long)p->state_spacing);
   return CPMPC_OK;
 }
 
@@ -499,7 +498,8 @@ static void launch_linearize(const SolverArgs<R, M>& a, int SP, const XV<R, M::N
     CPMPC_LIN(8)
     CPMPC_LIN(10)
     CPMPC_LIN(20)
-    default:
+    default:  // no register-resident specialisation: run-time spacing, Gamma accumulated in the workspace
+      hipLaunchKernelGGL((linearize_dyn_kernel<R, M>), grid, dim3(64), 0, stream, a, zx_in, zu_in, status);
       break;
   }
 #undef CPMPC_LIN

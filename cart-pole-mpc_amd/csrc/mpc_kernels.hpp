@@ -325,6 +325,81 @@ __global__ CPMPC_LIN_BOUNDS void linearize_kernel(const SolverArgs<R, M> a, cons
 }
 
 // ------------------------------------------------------------------------------------------------
+// linearize for a state spacing without a register-resident specialisation: the same forward
+// accumulation with the spacing a run-time value and the Gamma columns of the interval kept in the
+// workspace (each thread re-reads and re-writes only its own elements, coalesced over the wave).
+// O(SP^2) vector read-modify-writes per interval: correct for any spacing, not fast for long ones.
+// ------------------------------------------------------------------------------------------------
+template <typename R, typename M>
+__global__ __launch_bounds__(64) void linearize_dyn_kernel(const SolverArgs<R, M> a, const XV<R, M::NX>* zx_in,
+                                                           const R* zu_in, const int32_t* status) {
+  constexpr int NX = M::NX;
+  const int SP = a.SP;
+  const int64_t gid = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const int s = (int)(gid / a.B);
+  const unsigned p = (unsigned)(gid - (int64_t)s * a.B);
+  if (s >= a.S - 1) return;
+  const int64_t st = a.stride;
+  if (status != nullptr && status[IS_STATUS * st + p] != kTermNone) return;
+  const typename M::Consts k = load_consts(a, p);
+  const ExtForce<R> fe{R(0), R(0), R(0)};
+
+  R x[NX], xe[NX];
+  unpack<R, NX>(zx_in[(int64_t)s * st + p], x);
+  unpack<R, NX>(zx_in[(int64_t)(s + 1) * st + p], xe);
+  R Phi[NX][NX];
+#pragma unroll
+  for (int r = 0; r < NX; ++r)
+#pragma unroll
+    for (int c = 0; c < NX; ++c) Phi[r][c] = (r == c) ? R(1) : R(0);
+
+  const R* zu = zu_in + (int64_t)s * SP * st;
+  XV<R, NX>* gam = a.Gam + (int64_t)s * SP * st;
+#pragma unroll 1
+  for (int i = 0; i < SP; ++i) {
+    const R u = zu[(int64_t)i * st + p];
+    R A[NX][NX], Bv[NX];
+    rk4_step_jac_m<R, M, false>(k, a.dt, x, u, fe, A, Bv);
+    R T[NX][NX];
+#pragma unroll
+    for (int r = 0; r < NX; ++r)
+#pragma unroll
+      for (int c = 0; c < NX; ++c) {
+        R acc = A[r][0] * Phi[0][c];
+#pragma unroll
+        for (int m = 1; m < NX; ++m) acc += A[r][m] * Phi[m][c];
+        T[r][c] = acc;
+      }
+#pragma unroll
+    for (int r = 0; r < NX; ++r)
+#pragma unroll
+      for (int c = 0; c < NX; ++c) Phi[r][c] = T[r][c];
+#pragma unroll 1
+    for (int j = 0; j < i; ++j) {
+      R g[NX], gn[NX];
+      unpack<R, NX>(gam[(int64_t)j * st + p], g);
+#pragma unroll
+      for (int r = 0; r < NX; ++r) {
+        R acc = A[r][0] * g[0];
+#pragma unroll
+        for (int m = 1; m < NX; ++m) acc += A[r][m] * g[m];
+        gn[r] = acc;
+      }
+      gam[(int64_t)j * st + p] = pack<R, NX>(gn);
+    }
+    gam[(int64_t)i * st + p] = pack<R, NX>(Bv);
+  }
+  wrap_angles<R, M>(x);
+  R c[NX];
+#pragma unroll
+  for (int t = 0; t < NX; ++t) c[t] = x[t] - xe[t];
+  wrap_angles<R, M>(c);
+  a.cs[(int64_t)s * st + p] = pack<R, NX>(c);
+#pragma unroll
+  for (int r = 0; r < NX; ++r) a.Phi[(int64_t)(NX * s + r) * st + p] = pack<R, NX>(Phi[r]);
+}
+
+// ------------------------------------------------------------------------------------------------
 // merit evaluation at z (+) alpha dz: 1/2 |r|^2 and |c|_1 through the retraction
 // (optimization.cc:309-329) and a no-Jacobian rollout of every interval (optimization.cc:130-139).
 // ------------------------------------------------------------------------------------------------

@@ -112,13 +112,15 @@ typedef struct cpmpc_solver cpmpc_solver;
 
 /* Replaces Optimization::Optimization(const OptimizationParams&) (optimization.cc:13-22), for a
  * batch of up to `max_batch` independent controllers on HIP device `device`.  The reference's
- * constructor preconditions give CPMPC_ERR_INVALID_ARG.  state_spacing values built into the
- * library: see cpmpc_supported_state_spacing(). */
+ * constructor preconditions give CPMPC_ERR_INVALID_ARG.  Any state_spacing that divides window_length is
+ * accepted (optimization.cc:16-18); which ones have specialised kernels: cpmpc_supported_state_spacing(). */
 int cpmpc_create(const cpmpc_params* params, const cpmpc_solver_opts* opts /*nullable*/, int dtype,
                  int64_t max_batch, int device, cpmpc_solver** out);
 void cpmpc_destroy(cpmpc_solver* s);
 
-int cpmpc_supported_state_spacing(int spacing); /* 1 if kernels for it are compiled in */
+/* 2: register-resident linearisation compiled for this spacing (1,2,4,5,8,10,20); 1: served by the generic
+ * run-time-spacing kernel; 0: not a valid spacing */
+int cpmpc_supported_state_spacing(int spacing);
 
 /* Inputs of one batched re-plan.  Exactly one of dyn_shared_host / dyn must be non-NULL. */
 typedef struct cpmpc_step_inputs {

@@ -53,8 +53,10 @@ def test_params_mirror_reference_defaults(lib, pkg, orc):
 
 def test_supported_spacings(lib):
     for sp in (1, 2, 4, 5, 8, 10, 20):
-        assert lib.cpmpc_supported_state_spacing(sp) == 1
-    assert lib.cpmpc_supported_state_spacing(3) == 0
+        assert lib.cpmpc_supported_state_spacing(sp) == 2     # specialised kernels
+    for sp in (3, 6, 7, 15, 40):
+        assert lib.cpmpc_supported_state_spacing(sp) == 1     # generic run-time-spacing kernel
+    assert lib.cpmpc_supported_state_spacing(0) == 0 and lib.cpmpc_supported_state_spacing(-1) == 0
 
 
 def test_kernel_names(lib, pkg):
@@ -71,7 +73,9 @@ def test_create_validates_like_the_reference_constructor(lib, pkg):
         rc = lib.cpmpc_create(C.byref(p), None, pkg.capi.F32, 64, 0, C.byref(h))
         assert rc == pkg.capi.ERR_INVALID_ARG, bad
         assert lib.cpmpc_last_error()
-    p = pkg.default_params(state_spacing=40)  # valid in the reference, no kernel built for it
+    p = pkg.default_params(state_spacing=40)  # valid in the reference: accepted (generic kernel); here it gets as far
+    assert lib.cpmpc_create(C.byref(p), None, pkg.capi.F32, 64, 0, C.byref(h)) == pkg.capi.ERR_NO_DEVICE  # as the device
+    p = pkg.default_params(window_length=8192, state_spacing=8192)
     assert lib.cpmpc_create(C.byref(p), None, pkg.capi.F32, 64, 0, C.byref(h)) == pkg.capi.ERR_UNSUPPORTED
     p = pkg.default_params()
     assert lib.cpmpc_create(C.byref(p), None, 7, 64, 0, C.byref(h)) == pkg.capi.ERR_INVALID_ARG

@@ -137,7 +137,8 @@ def test_simulator_matches_oracle(pkg, orc):
 # ------------------------------------------------------------------------------------------------
 # a5: shooting constraints + chain rule
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("N,sp", [(40, 10), (40, 5), (20, 10), (40, 20), (8, 1), (8, 2), (16, 4), (16, 8)])
+@pytest.mark.parametrize("N,sp", [(40, 10), (40, 5), (20, 10), (40, 20), (8, 1), (8, 2), (16, 4), (16, 8),
+                                  (30, 3), (30, 6), (30, 15), (21, 7), (40, 40)])   # second row: generic kernel
 def test_linearize_matches_oracle(pkg, orc, N, sp):
     S = N // sp + 1
     rng = np.random.default_rng(N * 100 + sp)
@@ -209,6 +210,10 @@ def test_step_parity_default_exits(pkg, orc):
     dict(window_length=40, state_spacing=20, max_iterations=4),
     dict(window_length=16, state_spacing=8, max_iterations=4),
     dict(window_length=8, state_spacing=1, max_iterations=4),                         # pure multiple shooting
+    dict(window_length=30, state_spacing=3, max_iterations=4),                        # spacings served by the generic kernel
+    dict(window_length=30, state_spacing=15, max_iterations=4),
+    dict(window_length=21, state_spacing=7, max_iterations=4),
+    dict(window_length=40, state_spacing=40, max_iterations=4),                       # single shooting: one interval
     dict(max_iterations=30, u_cost_weight=0.0, b_x_final_cost_weight=5.0, absolute_first_derivative_tol=1e-3,
          b_x_dot_final_cost_weight=100.0, th_dot_final_cost_weight=100.0),            # model/scratch.py:26-36
     dict(max_iterations=5, th_final_cost_weight=50.0, b_x_dot_final_cost_weight=0.0,
