@@ -64,9 +64,72 @@ def cpu_baseline(x0_np, over, seconds_target=15.0):
     t0 = time.perf_counter()
     u, _, st, _, used = orc.step_batch_cold(p, DYN_UI, 0.0, x0_np[:, :n], num_threads=cores)
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "re-plans/s", "cores": int(used), "kind": "port",
+    n1 = min(128, x0_np.shape[1])
+    t1 = time.perf_counter()
+    orc.step_batch_cold(p, DYN_UI, 0.0, x0_np[:, :n1], num_threads=1)
+    one = n1 / (time.perf_counter() - t1)
+    return {"value": n / dt, "unit": "re-plans/s", "cores": int(used), "kind": "port", "one_core_value": one,
             "sample": "first %d problems of rank 0's batch, same N=40/5-iteration cold-start workload, fp64, "
                       "oracle/cpmpc_oracle.c with OpenMP, %.1f s" % (n, dt)}, u, n
+
+
+def variants(pkg, args, tdt, dev, local_rank, x0, B):
+    """Secondary measurements of SURVEY.md 8(d), outside the timed region and never `value`:
+    (1) the same cold-start re-plan with the reference's exit tolerances enabled (optimization.hpp:30-34:
+        lanes stop at SATISFIED_RELATIVE_TOL / SATISFIED_FIRST_ORDER_TOL; a wave ends with its last lane);
+    (2) closed loop: 50 MPC ticks = warm-started re-plan + batched Simulator step (10 RK4 sub-steps), all
+        state resident on the GPU (simulator.cc:11-36, optimization.cc:50-57)."""
+    res = {}
+    p1 = pkg.default_params(max_iterations=args.iters)
+    opt = pkg.BatchOptimization(p1, max_batch=B, dtype=tdt, device=local_rank)
+    opt.set_pipeline(args.pipeline)
+    out = pkg.BatchOutputs()
+    for _ in range(2):
+        opt.reset()
+        opt.step(x0, DYN_UI, 0.0, want_predicted=True, want_stats=True, out=out)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        opt.reset()
+        o = opt.step(x0, DYN_UI, 0.0, want_predicted=True, want_stats=True, out=out)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    st = o.status.cpu().numpy()
+    res["exits_enabled"] = {"re-plans/s": B / dt, "ms_per_step": dt * 1e3,
+                            "mean_iterations": float(o.iterations.float().mean().item()),
+                            "status_histogram": {pkg.capi.TERM_NAMES[int(c)]: int((st == c).sum()) for c in np.unique(st)},
+                            "note": "cold start, max_iterations=%d, relative_exit_tol=1e-5, "
+                                    "absolute_first_derivative_tol=1e-6 (reference defaults)" % args.iters}
+    # closed loop from near-upright states: re-plan (warm after the first tick) -> apply u_0 -> plant step
+    ticks = 50
+    rng = np.random.default_rng(7)
+    xs = np.stack([rng.uniform(-0.3, 0.3, B), np.pi / 2 + rng.uniform(-0.4, 0.4, B), rng.uniform(-0.5, 0.5, B),
+                   rng.uniform(-1, 1, B)])
+    sim = pkg.BatchSimulator(B, dtype=tdt, device=local_rank)
+    sim.set_state(torch.tensor(xs, dtype=tdt, device=dev))
+    opt = pkg.BatchOptimization(pkg.default_params(), max_batch=B, dtype=tdt, device=local_rank)
+    opt.set_pipeline(args.pipeline)
+    its = 0.0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(ticks):
+        o = opt.step(sim.get_state(), DYN_UI, 0.0, want_predicted=False, want_stats=True, out=out)
+        sim.step(DYN_UI, 0.01, o.u[0].contiguous())
+        if k >= ticks - 10:
+            its += o.iterations.float().mean().item() / 10
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / ticks
+    fin = sim.get_state()
+    err = (fin[1] - np.pi / 2).abs()
+    res["closed_loop_warm_start"] = {"ticks/s (controllers x ticks)": B / dt, "ms_per_tick": dt * 1e3, "ticks": ticks,
+                                     "mean_iterations_last_10_ticks": its,
+                                     "median_abs_pole_angle_error_after_0.5s": float(err.median().item()),
+                                     "fraction_within_0.1rad_after_0.5s": float((err < 0.1).float().mean().item()),
+                                     "note": "reference defaults (8 iterations max, exits enabled), warm start from the "
+                                             "shifted previous solution, plant = 10 RK4 sub-steps per tick, states "
+                                             "start within 0.4 rad of upright"}
+    return res
 
 
 def main():
@@ -79,6 +142,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the secondary measurements (SURVEY 8d)")
     ap.add_argument("--pipeline", choices=["auto", "split", "fused"], default="auto")
     args = ap.parse_args()
 
@@ -209,6 +273,8 @@ def main():
     st = out.status.cpu().numpy()
     line["status_histogram"] = {pkg.capi.TERM_NAMES[int(c)]: int((st == c).sum()) for c in np.unique(st)}
     line["mean_merit_evals_per_iter"] = float(out.ls_evals.float().mean().item() / args.iters)
+    if world == 1 and not args.no_variants:
+        line["variants"] = variants(pkg, args, tdt, dev, local_rank, x0, B)
     if not args.no_cpu_baseline and world == 1:
         base, u_cpu, n = cpu_baseline(x0_np, over)
         line["cpu_baseline"] = base
