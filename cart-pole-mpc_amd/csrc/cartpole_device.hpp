@@ -38,6 +38,7 @@ struct Math<float> {
 #if CPMPC_F32_LIBM
   static __device__ __forceinline__ void sincos(float x, float& s, float& c) { ::sincosf(x, &s, &c); }
   static __device__ __forceinline__ float tanh(float x) { return ::tanhf(x); }
+  static __device__ __forceinline__ float tanh_scaled(float x, float scale, float) { return ::tanhf(x * scale); }
   static __device__ __forceinline__ float sqrt(float x) { return ::sqrtf(x); }
   static __device__ __forceinline__ float rcp(float x) { return 1.0f / x; }
 #else
@@ -70,6 +71,12 @@ struct Math<float> {
     const float r = (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);
     return ::copysignf(r, x);
   }
+  // tanh(x * scale) with k2 = -2 log2(e) scale precomputed: one multiply feeds v_exp_f32 directly
+  static __device__ __forceinline__ float tanh_scaled(float x, float /*scale*/, float k2) {
+    const float t = __builtin_amdgcn_exp2f(::fabsf(x) * k2);  // exp(-2 |x| scale), in (0, 1]
+    const float r = (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);
+    return ::copysignf(r, x);
+  }
   static __device__ __forceinline__ float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
   static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 #endif
@@ -84,6 +91,7 @@ template <>
 struct Math<double> {
   static __device__ __forceinline__ void sincos(double x, double& s, double& c) { ::sincos(x, &s, &c); }
   static __device__ __forceinline__ double tanh(double x) { return ::tanh(x); }
+  static __device__ __forceinline__ double tanh_scaled(double x, double scale, double) { return ::tanh(x * scale); }
   static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
   static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
   static __device__ __forceinline__ double fabs(double x) { return ::fabs(x); }
@@ -124,6 +132,9 @@ struct CartPoleConsts {
   R gm1L;       // g * m_1 * L
   R half_cd;    // c_d / 2
   R half_cd_L;  // c_d L / 2
+  R tanh_k2;    // -2 log2(e) / v_mu   (fp32 tanh: exp2 argument scale)
+  R fr_vmu;     // fr / v_mu           (slope scale of the friction term)
+  R two_m1L;    // 2 m_1 L
 };
 
 template <typename R, typename P>
@@ -147,6 +158,9 @@ __host__ __device__ inline CartPoleConsts<R> make_consts(const P* p) {
   k.gm1L = R(g * m_1 * L);
   k.half_cd = R(P(0.5) * cd);
   k.half_cd_L = R(P(0.5) * cd * L);
+  k.tanh_k2 = R(P(-2.8853900817779268) / v_mu);
+  k.fr_vmu = R(((mt * mu) * -g) / v_mu);
+  k.two_m1L = R(P(2) * m_1 * L);
   return k;
 }
 
@@ -178,7 +192,7 @@ __device__ __forceinline__ void cartpole_accel(const CartPoleConsts<R>& k, const
   const R F_s = k.ks * ((on_l ? e_l : R(0)) - (on_r ? e_r : R(0)));
 
   // smoothed Coulomb friction
-  const R tv = Math<R>::tanh(v * k.inv_v_mu);
+  const R tv = Math<R>::tanh_scaled(v, k.inv_v_mu, k.tanh_k2);
   const R F_f = tv * k.fr;
 
   // air drag on the pole mass
@@ -187,10 +201,10 @@ __device__ __forceinline__ void cartpole_accel(const CartPoleConsts<R>& k, const
   const R vy = Lw * c;
   const R n2 = vx * vx + vy * vy;
   const R n = Math<R>::sqrt(n2);
-  const bool on_d = R(0) < n2;
   const R e = Lw - s * v;  // = c*vy - s*vx
-  const R Dx = on_d ? k.half_cd * n * vx : R(0);
-  const R Dth = on_d ? k.half_cd_L * n * e : R(0);
+  // the generated code guards these with |v|^2 > 0; at |v| = 0 the products are 0 anyway
+  const R Dx = k.half_cd * n * vx;
+  const R Dth = k.half_cd_L * n * e;
 
   R F_b = u + F_f + F_s - Dx + k.m1L * w * w * c;
   R F_th = -k.gm1L * c - Dth;
@@ -208,27 +222,25 @@ __device__ __forceinline__ void cartpole_accel(const CartPoleConsts<R>& k, const
   a_th = N_th * inv_den;
 
   if (WITH_J) {
-    // partials of the drag terms with respect to (th, v, w)
-    R dDx0 = R(0), dDx1 = R(0), dDx2 = R(0), dDt0 = R(0), dDt1 = R(0), dDt2 = R(0);
-    if (on_d) {
-      const R inv_n = Math<R>::rcp(n);
-      // d|v|/d(th, v, w), with  vx + L w s = v  and  c vy - s vx = e  folded in
-      const R dn0 = -(vy * v) * inv_n;
-      const R dn1 = vx * inv_n;
-      const R dn2 = (k.L * e) * inv_n;
-      dDx0 = k.half_cd * (dn0 * vx - n * vy);
-      dDx1 = k.half_cd * (dn1 * vx + n);
-      dDx2 = k.half_cd * (dn2 * vx - n * (k.L * s));
-      dDt0 = k.half_cd_L * (dn0 * e - n * (c * v));
-      dDt1 = k.half_cd_L * (dn1 * e - n * s);
-      dDt2 = k.half_cd_L * (dn2 * e + n * k.L);
-    }
-    const R dFf_dv = k.inv_v_mu * (R(1) - tv * tv) * k.fr;
+    // partials of the drag terms with respect to (th, v, w); all vanish at |v| = 0 (the guard of the
+    // generated code), which a zero 1/|v| reproduces without a branch
+    const R inv_n = (R(0) < n2) ? Math<R>::rcp(n) : R(0);
+    // d|v|/d(th, v, w), with  vx + L w s = v  and  c vy - s vx = e  folded in
+    const R dn0 = -(vy * v) * inv_n;
+    const R dn1 = vx * inv_n;
+    const R dn2 = (k.L * e) * inv_n;
+    const R dDx0 = k.half_cd * (dn0 * vx - n * vy);
+    const R dDx1 = k.half_cd * (dn1 * vx + n);
+    const R dDx2 = k.half_cd * (dn2 * vx - n * (k.L * s));
+    const R dDt0 = k.half_cd_L * (dn0 * e - n * (c * v));
+    const R dDt1 = k.half_cd_L * (dn1 * e - n * s);
+    const R dDt2 = k.half_cd_L * (dn2 * e + n * k.L);
+    const R dFf_dv = (R(1) - tv * tv) * k.fr_vmu;
     const R dFs_dbx = k.ks * ((on_l ? R(-1) : R(0)) - (on_r ? R(1) : R(0)));
 
     const R dFb0 = -dDx0 - k.m1L * w * w * s;
     const R dFb1 = dFf_dv - dDx1;
-    const R dFb2 = -dDx2 + R(2) * k.m1L * w * c;
+    const R dFb2 = -dDx2 + k.two_m1L * w * c;
     R dFt0 = k.gm1L * s - dDt0;
     if (HAS_EXT) dFt0 += k.L * (-fe.fmx * c - fe.fmy * s);
     const R dFt1 = -dDt1;

@@ -519,6 +519,10 @@ static bool use_fused(const cpmpc_solver* s) {
   return true;
 }
 
+// The shared-parameters specialisation (model constants wave-uniform, in SGPRs) is used in fp32 only: the fp64
+// kernel already sits at the SGPR limit with its VGPR/AGPR file exhausted, and with the constants added to the
+// scalar pressure hipcc 7.2 produced wrong results for it (caught by the fp64 parity tests); there the constants
+// go through load_consts() into vector registers like per-problem parameters do.
 template <typename R, typename M>
 static void launch_fused(const SolverArgs<R, M>& a, int L, int SP, int max_iters, hipStream_t stream) {
   {
@@ -526,7 +530,7 @@ static void launch_fused(const SolverArgs<R, M>& a, int L, int SP, int max_iters
     const dim3 grid((unsigned)((a.B + ppw - 1) / ppw));
 #define CPMPC_FUSED(LV, SPV)                                                                                \
   if (L == LV && SP == SPV) {                                                                               \
-    if (a.dyn == nullptr)                                                                                   \
+    if (a.dyn == nullptr && sizeof(R) == 4)                                                                 \
       hipLaunchKernelGGL((fused_sqp_kernel<R, M, SPV, LV, true>), grid, dim3(64), 0, stream, a, max_iters);  \
     else                                                                                                    \
       hipLaunchKernelGGL((fused_sqp_kernel<R, M, SPV, LV, false>), grid, dim3(64), 0, stream, a, max_iters); \
