@@ -37,7 +37,7 @@ def build_lib(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     os.makedirs(LIB_DIR, exist_ok=True)
-    # -fno-slp-vectorize: on gfx950 a v_pk_fma_f32 issues at ~1.8x the cost of a v_fma_f32 (scratch/ubench/pk.hip),
+    # -fno-slp-vectorize: on gfx950 a v_pk_fma_f32 issues at ~1.8x the cost of a v_fma_f32 (tools/ubench/pk.hip),
     # so the SLP vectoriser's packing plus its pairing moves is a net loss here (measured 91M -> 104M re-plans/s,
     # 255 -> 189 VGPRs for the fused SQP kernel)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC",
