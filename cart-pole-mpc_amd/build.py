@@ -12,11 +12,13 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libcpmpc.so")
 SOURCES = [os.path.join(CSRC, "cpmpc_api.hip")]
-DEPS = SOURCES + [
-    os.path.join(CSRC, "mpc_kernels.hpp"),
-    os.path.join(CSRC, "cartpole_device.hpp"),
-    os.path.join(HERE, "..", "include", "cpmpc.h"),
-]
+
+
+def _deps():
+    """Every file the library is compiled from: all of csrc/, the public header and this recipe (flags)."""
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp", ".h"))]
+    return files + [os.path.join(HERE, "..", "include", "cpmpc.h"), os.path.abspath(__file__)]
+
 
 
 def _hipcc():
@@ -30,21 +32,32 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(d) > t for d in DEPS)
+    return any(os.path.getmtime(d) > t for d in _deps())
 
 
 def build_lib(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     os.makedirs(LIB_DIR, exist_ok=True)
+    import fcntl
+    with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:  # one builder at a time (torchrun ranks)
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not needs_build():
+            return LIB
+        return _compile(verbose)
+
+
+def _compile(verbose):
     # -fno-slp-vectorize: on gfx950 a v_pk_fma_f32 issues at ~1.8x the cost of a v_fma_f32 (tools/ubench/pk.hip),
     # so the SLP vectoriser's packing plus its pairing moves is a net loss here (measured 91M -> 104M re-plans/s,
     # 255 -> 189 VGPRs for the fused SQP kernel)
+    tmp = LIB + ".tmp.%d" % os.getpid()
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC",
-           "-o", LIB] + SOURCES
+           "-o", tmp] + SOURCES
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
+    os.replace(tmp, LIB)  # atomic: a concurrent loader never sees a half-written library
     return LIB
 
 

@@ -120,6 +120,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    if not os.path.exists(LIB_PATH) and "CPMPC_LIB" not in os.environ:
+        # not built yet (fresh checkout): build the product library itself -- this is not a fallback, there is none
+        try:
+            from . import build as _build
+            _build.build_lib()
+        except Exception as exc:  # no hipcc, compile error: report below with the reason
+            raise ImportError("%s is missing and building it failed: %s.  There is no CPU fallback." % (LIB_PATH, exc))
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
