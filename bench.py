@@ -279,9 +279,19 @@ def main():
         base, u_cpu, n = cpu_baseline(x0_np, over)
         line["cpu_baseline"] = base
         err = np.abs(out.u[:, :n].double().cpu().numpy() - u_cpu).max(axis=0)
+        cl1 = out.final_eq_l1[:n].double().cpu().numpy()
+        conv = cl1 < 1e-3   # lanes whose shooting defects have closed after the fixed 5 iterations
         line["parity_sample"] = {"lanes": int(n), "max_abs_du_median": float(np.median(err)),
                                  "max_abs_du_p99": float(np.quantile(err, 0.99)), "max_abs_du_max": float(err.max()),
-                                 "note": "GPU %s vs fp64 oracle on the cpu_baseline sample" % args.dtype}
+                                 "fraction_within_1e-2": float((err < 1e-2).mean()),
+                                 "converged_lanes": int(conv.sum()),
+                                 "max_abs_du_median_on_converged_lanes": float(np.median(err[conv])) if conv.any() else None,
+                                 "max_abs_du_max_on_converged_lanes": float(err[conv].max()) if conv.any() else None,
+                                 "note": "GPU %s vs fp64 oracle on the cpu_baseline sample; these cold-start swing-up "
+                                         "problems are far from converged after 5 iterations (median |c|_1 %.1f) and the "
+                                         "SQP iteration amplifies rounding differences there, so the fp32-vs-fp64 gap is "
+                                         "reported overall and on the lanes that did converge; the parity bar is the "
+                                         "fp64 one below" % (args.dtype, float(np.median(cl1)))}
         line["gpu_over_cpu"] = value / base["value"]
         # the parity dtype: the same kernels in fp64 on the first lanes of the batch against the fp64 oracle
         # (north_star's 1e-5 bar on the control sequence; tests/test_gpu_parity.py is the gate, this is the record)
