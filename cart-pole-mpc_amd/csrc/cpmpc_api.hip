@@ -508,7 +508,8 @@ static void launch_linearize(const SolverArgs<R, M>& a, int SP, const XV<R, M::N
 // fused pipeline: built for both models and these (L = S-1, SP) pairs
 static bool fused_built(int model, int L, int SP) {
   (void)model;
-  return (L == 4 && SP == 10) || (L == 8 && SP == 5) || (L == 2 && SP == 10) || (L == 4 && SP == 5);
+  return (L == 4 && SP == 10) || (L == 8 && SP == 5) || (L == 2 && SP == 10) || (L == 4 && SP == 5) ||
+         (L == 8 && SP == 10) || (L == 16 && SP == 10) || (L == 16 && SP == 5);  // horizons of 80 and 160 steps
 }
 static bool use_fused(const cpmpc_solver* s) {
   if (s->pipeline == CPMPC_PIPELINE_SPLIT) return false;
@@ -540,6 +541,9 @@ static void launch_fused(const SolverArgs<R, M>& a, int L, int SP, int max_iters
     CPMPC_FUSED(8, 5)
     CPMPC_FUSED(2, 10)
     CPMPC_FUSED(4, 5)
+    CPMPC_FUSED(8, 10)
+    CPMPC_FUSED(16, 10)
+    CPMPC_FUSED(16, 5)
 #undef CPMPC_FUSED
   }
 }
