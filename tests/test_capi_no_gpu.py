@@ -31,6 +31,36 @@ def test_header_symbols_are_exported(lib, pkg):
         assert hasattr(raw, name), name
 
 
+def test_header_is_plain_c_and_struct_layouts_match(lib, pkg, tmp_path):
+    """include/cpmpc.h compiles as C99 (the boundary is a C-ABI: cgo / JNI / ctypes bind it) and the ctypes
+    mirrors in capi.py have the sizes and field offsets the C compiler gives the structs."""
+    import subprocess
+    src = tmp_path / "abi.c"
+    fields = {
+        "cpmpc_params": [f for f, _ in pkg.capi.Params._fields_],
+        "cpmpc_solver_opts": [f for f, _ in pkg.capi.SolverOpts._fields_],
+        "cpmpc_step_inputs": [f for f, _ in pkg.capi.StepInputs._fields_],
+        "cpmpc_step_outputs": [f for f, _ in pkg.capi.StepOutputs._fields_],
+    }
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "cpmpc.h"', "int main(void) {"]
+    for st, fs in fields.items():
+        lines.append('  printf("%s %%zu\\n", sizeof(%s));' % (st, st))
+        for f in fs:
+            lines.append('  printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (st, f, st, f))
+    lines += ["  return 0;", "}"]
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                           "-o", str(exe), str(src)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
+    mirrors = {"cpmpc_params": pkg.capi.Params, "cpmpc_solver_opts": pkg.capi.SolverOpts,
+               "cpmpc_step_inputs": pkg.capi.StepInputs, "cpmpc_step_outputs": pkg.capi.StepOutputs}
+    for st, cls in mirrors.items():
+        assert int(got[st]) == C.sizeof(cls), st
+        for f, _ in cls._fields_:
+            assert int(got["%s.%s" % (st, f)]) == getattr(cls, f).offset, (st, f)
+
+
 def test_params_mirror_reference_defaults(lib, pkg, orc):
     """optimization/optimization.hpp:12-48, field for field, and equal to the oracle's mirror."""
     p = pkg.default_params()
