@@ -297,8 +297,9 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
         }
         const R n0 = Tsp.a * pq0 + Tsp.b * pq1;
         const R n1 = Tsp.c * pq0 + Tsp.d * pq1;
-        pq0 = n0;
-        pq1 = n1;
+        // delta = p / q is scale invariant: renormalise, or (p, q) ~ 2^-k would leave the fp32 range on long horizons
+        pq0 = n0 * Math<R>::rcp(n1);
+        pq1 = R(1);
       }
       id_right = (myq * rb) / myp;  // 1 / (b delta)
     }

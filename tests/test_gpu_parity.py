@@ -525,6 +525,25 @@ def test_long_horizons_fused(pkg, orc, over):
     assert (np.abs(N_(out2.u) - N_(out.u)).max(axis=0)[same] < tol).mean() > 0.97
 
 
+def test_long_horizon_fp32_stays_finite(pkg):
+    """fp32 at a 160-step horizon: state elimination through 1.6 s of an unstable plant is too ill-conditioned for
+    single precision (both pipelines report QP_INDEFINITE on some lanes and differ on others; use fp64 there), but
+    nothing may overflow or turn into NaN: with w_u = 0 the pivot recurrence's matrix powers decay like 2^-150,
+    outside fp32's normal range unless the (p, q) pair is renormalised."""
+    rng = np.random.default_rng(12)
+    x0 = random_states(rng, 64)
+    x0[1] = np.pi / 2 + rng.uniform(-0.05, 0.05, 64)
+    over = dict(window_length=160, state_spacing=10, max_iterations=2, u_cost_weight=0.0)
+    for pipe in ("fused", "split"):
+        opt = pkg.BatchOptimization(pkg.default_params(**over), max_batch=64, dtype=torch.float32, device=0)
+        opt.set_pipeline(pipe)
+        out = opt.step(T(x0, torch.float32), DYN_UI, 0.0)
+        assert torch.isfinite(out.u).all() and torch.isfinite(out.predicted_states).all()
+        st = set(N_(out.status).tolist())
+        assert st <= {pkg.capi.TERM["MAX_ITERATIONS"], pkg.capi.TERM["QP_INDEFINITE"]}, st
+        assert (out.status == pkg.capi.TERM["MAX_ITERATIONS"]).float().mean().item() > 0.5
+
+
 @pytest.mark.parametrize("over", [dict(NO_TOL), dict(), dict(state_spacing=5, max_iterations=6),
                                   dict(window_length=20, max_iterations=6),
                                   dict(window_length=20, state_spacing=5, max_iterations=6)])
