@@ -101,6 +101,25 @@ def variants(pkg, args, tdt, dev, local_rank, x0, B):
                             "status_histogram": {pkg.capi.TERM_NAMES[int(c)]: int((st == c).sum()) for c in np.unique(st)},
                             "note": "cold start, max_iterations=%d, relative_exit_tol=1e-5, "
                                     "absolute_first_derivative_tol=1e-6 (reference defaults)" % args.iters}
+    # (1b) the workload of the timed region with the alternative step-length memory ("what would move it
+    #      next"): grow the step only after a first-trial accept.  Faster per iteration, slightly less progress.
+    pa = pkg.default_params(max_iterations=args.iters, relative_exit_tol=0.0, absolute_first_derivative_tol=0.0)
+    for name, so in (("default", None), ("ls_alpha_growth_backtracked=1", pkg.capi.default_solver_opts(ls_alpha_growth_backtracked=1.0))):
+        o2 = pkg.BatchOptimization(pa, max_batch=B, dtype=tdt, device=local_rank, opts=so)
+        o2.set_pipeline(args.pipeline)
+        for _ in range(2):
+            o2.reset()
+            o2.step(x0, DYN_UI, 0.0, want_predicted=True, want_stats=True, out=out)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            o2.reset()
+            o = o2.step(x0, DYN_UI, 0.0, want_predicted=True, want_stats=True, out=out)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        res.setdefault("step_length_memory", {})[name] = {
+            "re-plans/s": B / dt, "mean_merit_evals_per_iter": float(o.ls_evals.float().mean().item() / args.iters),
+            "median_final_eq_l1": float(o.final_eq_l1.median().item()), "median_final_cost": float(o.final_cost.median().item())}
     # closed loop from near-upright states: re-plan (warm after the first tick) -> apply u_0 -> plant step
     ticks = 50
     rng = np.random.default_rng(7)
