@@ -509,7 +509,8 @@ static void launch_linearize(const SolverArgs<R, M>& a, int SP, const XV<R, M::N
 static bool fused_built(int model, int L, int SP) {
   (void)model;
   return (L == 4 && SP == 10) || (L == 8 && SP == 5) || (L == 2 && SP == 10) || (L == 4 && SP == 5) ||
-         (L == 8 && SP == 10) || (L == 16 && SP == 10) || (L == 16 && SP == 5);  // horizons of 80 and 160 steps
+         (L == 8 && SP == 10) || (L == 16 && SP == 10) || (L == 16 && SP == 5) ||  // horizons of 80 and 160 steps
+         (L == 2 && SP == 20);
 }
 static bool use_fused(const cpmpc_solver* s) {
   if (s->pipeline == CPMPC_PIPELINE_SPLIT) return false;
@@ -544,6 +545,7 @@ static void launch_fused(const SolverArgs<R, M>& a, int L, int SP, int max_iters
     CPMPC_FUSED(8, 10)
     CPMPC_FUSED(16, 10)
     CPMPC_FUSED(16, 5)
+    CPMPC_FUSED(2, 20)
 #undef CPMPC_FUSED
   }
 }

@@ -589,8 +589,8 @@ def test_pipeline_selection(pkg):
     assert opt.pipeline() == "fused"                   # (S-1, state_spacing) = (4, 10) is built
     opt.set_pipeline("split")
     assert opt.pipeline() == "split"
-    opt2 = pkg.BatchOptimization(pkg.default_params(state_spacing=20), max_batch=64, dtype=torch.float32, device=0)
-    assert opt2.pipeline() == "split"
+    opt2 = pkg.BatchOptimization(pkg.default_params(state_spacing=8), max_batch=64, dtype=torch.float32, device=0)
+    assert opt2.pipeline() == "split"                  # 5 intervals do not divide a 16-lane DPP row: not built
     with pytest.raises(pkg.CpmpcError) as ei:
         opt2.set_pipeline("fused")
     assert ei.value.code == pkg.capi.ERR_UNSUPPORTED
