@@ -46,6 +46,41 @@ def test_dynamics_golden_vectors(pkg, golden_dynamics):
             assert np.abs(got - want).max() / max(1.0, np.abs(want).max()) < 1e-12, c["tag"]
 
 
+def test_fp64_math_routines_over_wide_ranges(pkg, orc):
+    """The fp64 kernels use their own bounded-range sincos / tanh (cartpole_device.hpp); the oracle uses the C
+    library.  Angles from 1e-6 rad to hundreds of turns and exactly at multiples of pi/2 (worst case of the argument
+    reduction), friction arguments from 1e-11 to 1e4: f and J agree to a few ulp, scaled by the size of the terms."""
+    rng = np.random.default_rng(3)
+    B = 4096
+    x = np.zeros((4, B))
+    x[0] = rng.uniform(-1.2, 1.2, B)
+    x[1] = rng.uniform(-np.pi, np.pi, B) * 10.0 ** rng.integers(-6, 3, B)
+    x[2] = rng.standard_normal(B) * 10.0 ** rng.integers(-12, 3, B)
+    x[3] = rng.standard_normal(B) * 10.0 ** rng.integers(-8, 2, B)
+    x[1, :512] = np.round(rng.uniform(-50, 50, 512)) * (np.pi / 2)
+    x[2, 512:520] = [0.0, -0.0, 1e-300, -1e-300, 4.0, -4.0, 1e3, -1e3]
+    u = rng.uniform(-50, 50, B)
+    f, Jx, Ju = pkg.dynamics_batch(DYN_UI, T(x), T(u))
+    f, Jx = N_(f), N_(Jx)
+    for b in range(B):
+        fo, Jo, _ = orc.dynamics(DYN_UI, x[:, b], u[b])
+        scale = max(1.0, np.abs(fo).max())
+        assert np.abs(f[:, b] - fo).max() <= 2e-13 * scale, (b, x[:, b])
+        assert np.abs(Jx[:, :, b] - Jo).max() <= 2e-13 * max(1.0, np.abs(Jo).max()), (b, x[:, b])
+    # odd symmetry of the friction term is exact: f(-v) mirrored
+    xm = x.copy()
+    xm[1] = 0.3
+    xm[3] = 0.0
+    xm[0] = 0.0
+    fa, _, _ = pkg.dynamics_batch([1.0, 0.1, 0.25, 0.0, 0.05, 0.1, 0.0, 0.8, 100.0], T(xm), T(np.zeros(B)))
+    xm[2] = -xm[2]
+    fb, _, _ = pkg.dynamics_batch([1.0, 0.1, 0.25, 0.0, 0.05, 0.1, 0.0, 0.8, 100.0], T(xm), T(np.zeros(B)))
+    assert torch.equal(fa[2], -fb[2])
+    bad = np.array([[0.0, np.inf, 0.0, 0.0], [0.0, 1e300, 0.0, 0.0], [0.0, np.nan, 0.0, 0.0]]).T
+    fn, _, _ = pkg.dynamics_batch(DYN_UI, T(bad), T(np.zeros(3)))
+    assert not torch.isfinite(fn[2:]).any()          # a state no lane can hold: non-finite out, never garbage
+
+
 def test_survey_known_answers(pkg, survey_answers):
     k = survey_answers
     x, u = T(np.array(k["x"]).reshape(4, 1)), T([k["u"]])
