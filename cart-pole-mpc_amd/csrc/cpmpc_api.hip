@@ -608,7 +608,7 @@ static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* 
   }
 
   span_begin(s, CPMPC_KERNEL_FINALIZE, stream, &sp);
-  hipLaunchKernelGGL((finalize_kernel<R, M>), gridB, dim3(64), 0, stream, a);
+  hipLaunchKernelGGL((finalize_kernel<R, M>), dim3((unsigned)((B + 255) / 256)), dim3(256), 0, stream, a);
   span_end(s, stream, &sp);
 
   HIP_TRY(hipGetLastError());
