@@ -297,6 +297,47 @@ def test_step_parity_solver_options(pkg, orc, sopts, pipeline):
     assert err.max() < 1e-5, np.sort(err)[-5:]
 
 
+def _random_case(rng):
+    N, sp = [(40, 10), (40, 5), (20, 10), (20, 5), (40, 20), (80, 10), (40, 8), (30, 6), (24, 3), (16, 16)][rng.integers(0, 10)]
+    sign = lambda w: float(w if rng.random() < 0.5 else -1.0)     # cost row or equality row
+    over = dict(
+        window_length=N, state_spacing=sp, max_iterations=int(rng.integers(2, 6)),
+        control_dt=float(rng.choice([0.005, 0.01, 0.02])),
+        relative_exit_tol=float(rng.choice([0.0, 1e-5, 1e-3])),
+        absolute_first_derivative_tol=float(rng.choice([0.0, 1e-6, 1e-2])),
+        equality_penalty_initial=float(10.0 ** rng.uniform(-1, 2)),
+        u_guess_sinusoid_amplitude=float(rng.choice([0.0, 3.0, 10.0])),
+        u_cost_weight=float(rng.choice([0.0, 0.01, 0.1, 1.0])),
+        u_derivative_cost_weight=float(rng.choice([0.0, 0.05, 0.1, 1.0])),
+        b_x_final_cost_weight=sign(10.0 ** rng.uniform(0, 2.5)),
+        th_final_cost_weight=sign(10.0 ** rng.uniform(0, 2.5)),
+        b_x_dot_final_cost_weight=sign(10.0 ** rng.uniform(0, 2)),
+        th_dot_final_cost_weight=sign(10.0 ** rng.uniform(0, 2)))
+    if over["u_cost_weight"] == 0.0 and over["u_derivative_cost_weight"] == 0.0:
+        over["u_cost_weight"] = 0.1                      # some control cost, or the QP is singular by construction
+    dyn = [float(rng.uniform(0.5, 2.0)), float(rng.uniform(0.05, 0.3)), float(rng.uniform(0.15, 0.5)), 9.81,
+           float(rng.choice([0.0, 0.05, 0.2])), float(rng.choice([1e-7, 0.05, 0.1])), float(rng.choice([0.0, 0.02, 0.1])),
+           float(rng.uniform(0.5, 1.0)), float(rng.choice([0.0, 50.0, 100.0]))]
+    return over, dyn, float(rng.uniform(-0.3, 0.3))
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_step_parity_fuzz(pkg, orc, seed):
+    """Seeded random problem definitions (horizons served by the fused, the split and the generic-spacing kernels;
+    cost/equality terminal rows in every mix; zero weights; friction / drag / bumpers on and off; exits on and off)
+    against the oracle, fp64: same termination state and iteration count, controls within 1e-5."""
+    rng = np.random.default_rng(1000 + seed)
+    over, dyn, sp = _random_case(rng)
+    B = 96
+    x0 = random_states(rng, B)
+    x0[1, ::2] = np.pi / 2 + rng.uniform(-0.4, 0.4, B // 2)
+    out, err, perr, st_ok, it_ok = _compare_step(pkg, orc, over, x0, dyn=dyn, set_point=sp)
+    good = st_ok & it_ok
+    assert good.mean() >= 0.95, (over, dyn)
+    assert (err[good] < 1e-5).mean() >= 0.97, (over, dyn, np.sort(err[good])[-5:])
+    assert np.median(err[good]) < 1e-8
+
+
 def test_edge_batches(pkg, orc):
     """B = 1, a ragged B, capacity errors, and the reference's scratch.py call sequence at B = 1."""
     rng = np.random.default_rng(3)
