@@ -660,6 +660,30 @@ def test_fused_and_split_pipelines_agree(pkg, orc, over, dtype):
         assert d1.median().item() < 1e-2
 
 
+def test_two_handles_on_two_streams(pkg):
+    """Handles are independent: two solvers stepping concurrently on two HIP streams give bitwise the results
+    they give one after the other (every launch of a step goes to the caller's current stream)."""
+    rng = np.random.default_rng(21)
+    B = 8192
+    xa, xb = T(random_states(rng, B), torch.float32), T(random_states(rng, B), torch.float32)
+    mk = lambda: pkg.BatchOptimization(pkg.default_params(**NO_TOL), max_batch=B, dtype=torch.float32, device=0)
+    ref_a, ref_b = mk().step(xa, DYN_UI, 0.0).u.clone(), mk().step(xb, DYN_UI, 0.1).u.clone()
+    torch.cuda.synchronize()
+    oa, ob = mk(), mk()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    outs_a, outs_b = [], []
+    for _ in range(3):
+        with torch.cuda.stream(sa):
+            oa.reset()
+            outs_a.append(oa.step(xa, DYN_UI, 0.0, out=pkg.BatchOutputs()).u)
+        with torch.cuda.stream(sb):
+            ob.reset()
+            outs_b.append(ob.step(xb, DYN_UI, 0.1, out=pkg.BatchOutputs()).u)
+    torch.cuda.synchronize()
+    for ua, ub in zip(outs_a, outs_b):
+        assert torch.equal(ua, ref_a) and torch.equal(ub, ref_b)
+
+
 def test_pipeline_selection(pkg):
     opt = pkg.BatchOptimization(pkg.default_params(), max_batch=64, dtype=torch.float32, device=0)
     assert opt.pipeline() == "fused"                   # (S-1, state_spacing) = (4, 10) is built
