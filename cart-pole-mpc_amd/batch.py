@@ -128,8 +128,10 @@ class BatchOptimization:
 
     # -- Optimization::Step -------------------------------------------------------------------
     def step(self, x0, dyn, set_point=0.0, want_predicted=True, want_stats=True, want_guess=False,
-             out=None):
-        """x0: [nx, B] tensor.  dyn: np floats (shared) or an [np, B] tensor.  set_point: float or [B]."""
+             out=None, terminal_weights=None):
+        """x0: [nx, B] tensor.  dyn: np floats (shared) or an [np, B] tensor.  set_point: float or [B].
+        terminal_weights: optional [nx, B] tensor of per-problem terminal weights in state order (>= 0 cost row,
+        < 0 equality row; optimization.cc:236-267), overriding the four *_final_cost_weight parameters."""
         lib = capi.load()
         dev = torch.device("cuda", self.device)
         _require_cuda_tensor(x0, "x0", self.dtype)
@@ -157,6 +159,12 @@ class BatchOptimization:
         else:
             inp.set_point = None
             inp.set_point_shared = float(set_point)
+        if terminal_weights is not None:
+            _require_cuda_tensor(terminal_weights, "terminal_weights", self.dtype, (self.nx, B))
+            inp.terminal_weights = terminal_weights.data_ptr()
+            keep.append(terminal_weights)
+        else:
+            inp.terminal_weights = None
 
         o = out if out is not None else BatchOutputs()
         if o.u is None or tuple(o.u.shape) != (self.N, B):

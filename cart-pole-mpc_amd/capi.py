@@ -88,6 +88,7 @@ class StepInputs(C.Structure):
         ("dyn", C.c_void_p),
         ("set_point_shared", C.c_double),
         ("set_point", C.c_void_p),
+        ("terminal_weights", C.c_void_p),
     ]
 
 

@@ -573,6 +573,7 @@ static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* 
   a.x0 = (const R*)in->x0;
   a.dyn = (const R*)in->dyn;
   a.set_point = (const R*)in->set_point;
+  a.term_w_pp = (const R*)in->terminal_weights;
   if (in->dyn == nullptr) a.consts = M::template make<double>(in->dyn_shared_host);
   a.term_tgt[0] = (R)in->set_point_shared;
   if (out) {

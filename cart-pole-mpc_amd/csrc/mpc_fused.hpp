@@ -187,9 +187,8 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
   for (int t = 0; t < NX; ++t) {
     tgt[t] = a.term_tgt[t];
     xm[t] = a.x0[t * a.B + p];
-    Rw[t] = a.term_w[t];
-    Dg[t] = ((a.term_is_cost >> t) & 1) ? R(1) : R(0);
   }
+  load_terminal<R, M>(a, p, Rw, Dg);
   if (a.set_point) tgt[0] = a.set_point[p];
 
   // ---- my piece of the iterate --------------------------------------------------------------------------
@@ -482,8 +481,8 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
 #pragma unroll
     for (int t = 0; t < NX; ++t) {
       cn += Math<R>::fabs(ci[t]);
-      if ((a.term_is_cost >> t) & 1) {
-        const R r = a.term_w[t] * e_term[t];
+      if (Dg[t] != R(0)) {
+        const R r = Rw[t] * e_term[t];
         f += r * r;
       } else {
         cn += Math<R>::fabs(e_term[t]);
@@ -649,9 +648,9 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
       for (int t = 0; t < NX; ++t) dxT[t] = group_last<R, L>(dxe[t], gbase);
 #pragma unroll
       for (int t = 0; t < NX; ++t) {
-        if ((a.term_is_cost >> t) & 1) {
-          const R jd = a.term_w[t] * dxT[t];
-          gd += (a.term_w[t] * e_term[t]) * jd;
+        if (Dg[t] != R(0)) {
+          const R jd = Rw[t] * dxT[t];
+          gd += (Rw[t] * e_term[t]) * jd;
           curv += jd * jd;
         }
       }
@@ -722,8 +721,8 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
         wrap_angles<R, M>(d);
 #pragma unroll
         for (int r = 0; r < NX; ++r) {
-          if ((a.term_is_cost >> r) & 1) {
-            const R rr = a.term_w[r] * d[r];
+          if (Dg[r] != R(0)) {
+            const R rr = Rw[r] * d[r];
             fp += rr * rr;
           } else {
             cp += Math<R>::fabs(d[r]);

@@ -142,6 +142,7 @@ struct SolverArgs {
   const R* x0;         // [NX]
   const R* dyn;        // [NP] per-problem, or nullptr
   const R* set_point;  // [1] per-problem, or nullptr
+  const R* term_w_pp;  // [NX] per-problem terminal weights in state order (negative = equality row), or nullptr
   typename M::Consts consts;  // shared model constants (used when dyn == nullptr)
   // outputs, packed [field][B] (nullable)
   R* u_out;
@@ -153,6 +154,25 @@ struct SolverArgs {
   R* eq_out;
   R* guess_out;
 };
+
+// Terminal rows of problem p (optimization.cc:236-267): residual weight Rw[t] (1 for an equality row) and
+// Dg[t] = 1 for a cost row (weight >= 0), 0 for an equality row.  Shared by the batch unless per-problem
+// weights were given (the UI's per-controller cost/constraint toggles, viz/src/application.ts:279-342).
+template <typename R, typename M>
+__device__ __forceinline__ void load_terminal(const SolverArgs<R, M>& a, unsigned p, R (&Rw)[M::NX], R (&Dg)[M::NX]) {
+#pragma unroll
+  for (int t = 0; t < M::NX; ++t) {
+    if (a.term_w_pp != nullptr) {
+      const R w = a.term_w_pp[(int64_t)t * a.B + p];
+      const bool is_cost = w >= R(0);
+      Rw[t] = is_cost ? w : R(1);
+      Dg[t] = is_cost ? R(1) : R(0);
+    } else {
+      Rw[t] = a.term_w[t];
+      Dg[t] = ((a.term_is_cost >> t) & 1) ? R(1) : R(0);
+    }
+  }
+}
 
 template <typename R, typename M>
 __device__ __forceinline__ typename M::Consts load_consts(const SolverArgs<R, M>& a, unsigned p) {
@@ -470,10 +490,12 @@ __device__ __forceinline__ void merit_eval(const SolverArgs<R, M>& a, const type
 #pragma unroll
     for (int t = 0; t < NX; ++t) d[t] = xs[t] - tgt[t];
     wrap_angles<R, M>(d);
+    R Rw[NX], Dg[NX];
+    load_terminal<R, M>(a, p, Rw, Dg);
 #pragma unroll
     for (int t = 0; t < NX; ++t) {
-      if ((a.term_is_cost >> t) & 1) {
-        const R r = a.term_w[t] * d[t];
+      if (Dg[t] != R(0)) {
+        const R r = Rw[t] * d[t];
         f += r * r;
       } else {
         cn += Math<R>::fabs(d[t]);
@@ -548,13 +570,12 @@ __global__ CPMPC_QPLS_BOUNDS void qp_ls_kernel(const SolverArgs<R, M> a) {
 #pragma unroll
     for (int t = 0; t < NX; ++t) e_term[t] = zt[t] - tgt[t];
     wrap_angles<R, M>(e_term);
+    load_terminal<R, M>(a, p, Rw, Dg);
 #pragma unroll
     for (int t = 0; t < NX; ++t) {
-      const bool is_cost = (a.term_is_cost >> t) & 1;
-      Rw[t] = a.term_w[t];
-      Dg[t] = is_cost ? R(1) : R(0);
+      const bool is_cost = Dg[t] != R(0);
       if (is_cost) {
-        const R r = a.term_w[t] * e_term[t];
+        const R r = Rw[t] * e_term[t];
         f += r * r;
       } else {
         cn += Math<R>::fabs(e_term[t]);
@@ -782,9 +803,9 @@ __global__ CPMPC_QPLS_BOUNDS void qp_ls_kernel(const SolverArgs<R, M> a) {
     }
 #pragma unroll
     for (int t = 0; t < NX; ++t) {
-      if ((a.term_is_cost >> t) & 1) {
-        const R jd = a.term_w[t] * dx[t];
-        gd += (a.term_w[t] * e_term[t]) * jd;
+      if (Dg[t] != R(0)) {
+        const R jd = Rw[t] * dx[t];
+        gd += (Rw[t] * e_term[t]) * jd;
         curv += jd * jd;
       }
     }

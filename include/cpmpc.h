@@ -129,6 +129,10 @@ typedef struct cpmpc_step_inputs {
   const void* dyn;               /* [9][B]  per-problem SingleCartPoleParams, or NULL */
   double set_point_shared;       /* b_x_set_point shared by the batch (used if set_point NULL) */
   const void* set_point;         /* [B]     per-problem b_x_set_point, or NULL */
+  /* [NX][B] per-problem terminal weights in state order {b_x, th.., b_x', th'..}, replacing the four *_final_cost_weight
+   * parameters for this call: >= 0 a cost row with that weight, < 0 an equality row (optimization.cc:236-267; the
+   * per-controller toggles of viz/src/application.ts:279-342).  NULL: the handle's parameters apply to every problem. */
+  const void* terminal_weights;
 } cpmpc_step_inputs;
 
 /* Outputs; every pointer is nullable. */

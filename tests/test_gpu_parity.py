@@ -379,6 +379,40 @@ def test_per_problem_parameters_and_set_points(pkg, orc):
         np.testing.assert_allclose(u[:, b], o.u, rtol=0, atol=1e-5)
 
 
+@pytest.mark.parametrize("pipeline", ["fused", "split"])
+def test_per_problem_terminal_weights(pkg, orc, pipeline):
+    """Every problem with its own terminal rows (cost <-> equality per sign, its own weights): the UI's per-controller
+    toggles (viz/src/application.ts:279-342) at batch scale.  Checked problem by problem against the oracle built
+    with those weights as its OptimizationParams; weights equal to the handle's parameters reproduce the shared path
+    bitwise."""
+    rng = np.random.default_rng(33)
+    B = 160
+    x0 = random_states(rng, B)
+    x0[1, ::2] = np.pi / 2 + rng.uniform(-0.4, 0.4, B // 2)
+    w = 10.0 ** rng.uniform(0, 2.3, (4, B))
+    w[rng.random((4, B)) < 0.5] = -1.0
+    names = ["b_x_final_cost_weight", "th_final_cost_weight", "b_x_dot_final_cost_weight", "th_dot_final_cost_weight"]
+    opt = pkg.BatchOptimization(pkg.default_params(**NO_TOL), max_batch=B, dtype=torch.float64, device=0)
+    opt.set_pipeline(pipeline)
+    out = opt.step(T(x0), DYN_UI, 0.05, terminal_weights=T(w))
+    u = N_(out.u)
+    st = N_(out.status)
+    bad = 0
+    for b in range(B):
+        over = dict(NO_TOL, **{n: float(w[t, b]) for t, n in enumerate(names)})
+        uc, _, sc, _, _ = orc.step_batch_cold(orc.default_opt_params(**over), DYN_UI, 0.05, x0[:, b:b + 1])
+        if sc[0] != st[b] or np.abs(u[:, b] - uc[:, 0]).max() >= 1e-5:
+            bad += 1
+    assert bad <= B // 50, bad
+    # the handle's own weights given per problem: bitwise the shared path
+    p = pkg.default_params(**NO_TOL)
+    shared = np.array([[getattr(p, n)] * B for n in names])
+    opt.reset()
+    a = opt.step(T(x0), DYN_UI, 0.05, terminal_weights=T(shared)).u.clone()
+    opt.reset()
+    assert torch.equal(a, opt.step(T(x0), DYN_UI, 0.05).u)
+
+
 def test_warm_start_closed_loop(pkg, orc):
     """Optimization::Step over consecutive ticks with the plant in the loop (optimization_test.cc:39-61),
     64 controllers at once: warm-start shift, u_prev bookkeeping and Simulator all on the GPU, compared
