@@ -113,6 +113,11 @@ PYBIND11_MODULE(pypendulum, m) {
       .def_static("from_json", &Vector2FromJson)
       .def_static("list_from_json", &Vector2ListFromJson);
   m.def("get_default_optimization_params", []() { return OptimizationParams{}; });  // wasm.cc:118-119
+  // wasm.cc:121-140: mini_opt's trace collector does not exist here; per-kernel timing is the batched API's
+  // profile_enable/profile_read (cpmpc_profile_*), so the facade reports tracing as off, as a build without
+  // MINI_OPT_TRACING does.
+  m.def("is_tracing_enabled", []() { return false; });
+  m.def("get_traces", []() { return std::string{}; });
 
   py::class_<Simulator>(m, "Simulator")
       .def(py::init<>())

@@ -76,6 +76,7 @@ def test_json_wire_format_of_the_structs(pp):
     integral values) -- for these magnitudes the same text as Python's compact sorted dump."""
     import json
     canon = lambda t: json.dumps(json.loads(t), sort_keys=True, separators=(",", ":"))
+    assert pp.is_tracing_enabled() is False and pp.get_traces() == ""   # wasm.cc:121-140 without MINI_OPT_TRACING
     p = pp.get_default_optimization_params()           # wasm.cc:118-119 getDefaultOptimizationParams
     t = p.to_json()
     assert t == canon(t)
