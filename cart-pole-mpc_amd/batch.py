@@ -239,6 +239,10 @@ class BatchOptimization:
         """'auto' | 'split' | 'fused' (include/cpmpc.h: CPMPC_PIPELINE_*)."""
         capi.check(capi.load().cpmpc_set_pipeline(self._h, capi.PIPELINES[mode]))
 
+    def set_compaction(self, first_iterations=3, next_iterations=1):
+        """Staging of the fused pipeline when exit tolerances are enabled (0, 0 = one launch).  Speed only."""
+        capi.check(capi.load().cpmpc_set_compaction(self._h, int(first_iterations), int(next_iterations)))
+
     def pipeline(self):
         return {capi.PIPELINE_SPLIT: "split", capi.PIPELINE_FUSED: "fused"}[capi.load().cpmpc_get_pipeline(self._h)]
 

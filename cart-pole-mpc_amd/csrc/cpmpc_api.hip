@@ -190,6 +190,10 @@ struct cpmpc_solver {
   double prof_ms[CPMPC_KERNEL_COUNT] = {0, 0, 0, 0, 0};
   int64_t prof_n[CPMPC_KERNEL_COUNT] = {0, 0, 0, 0, 0};
   int pipeline = CPMPC_PIPELINE_AUTO;
+  // staged fused pipeline (compaction of the still-active problems between stages); 0/0 = single launch
+  int stage_first = 3, stage_next = 1;
+  bool stage_auto = true;  // default: stage only batches larger than one round of resident waves
+  int32_t* active = nullptr;  // [cap] compacted problem indices, then one counter
 };
 
 // 2: a register-resident linearisation is compiled for this spacing; 1: served by the generic kernel
@@ -327,6 +331,7 @@ extern "C" void cpmpc_destroy(cpmpc_solver* s) {
   if (s->ws) (void)hipFree(s->ws);
   if (s->sin_table) (void)hipFree(s->sin_table);
   if (s->stage) (void)hipFree(s->stage);
+  if (s->active) (void)hipFree(s->active);
   delete s;
 }
 
@@ -560,6 +565,14 @@ extern "C" int cpmpc_set_pipeline(cpmpc_solver* s, int mode) {
   s->pipeline = mode;
   return CPMPC_OK;
 }
+extern "C" int cpmpc_set_compaction(cpmpc_solver* s, int first_iterations, int next_iterations) {
+  if (!s) return fail(CPMPC_ERR_INVALID_ARG, "null solver");
+  if (first_iterations < 0 || next_iterations < 0) return fail(CPMPC_ERR_INVALID_ARG, "iteration counts must be >= 0");
+  s->stage_first = first_iterations;
+  s->stage_next = next_iterations;
+  s->stage_auto = false;  // an explicit setting applies to every batch size
+  return CPMPC_OK;
+}
 extern "C" int cpmpc_get_pipeline(const cpmpc_solver* s) {
   if (!s) return -1;
   return use_fused(s) ? CPMPC_PIPELINE_FUSED : CPMPC_PIPELINE_SPLIT;
@@ -594,9 +607,39 @@ static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* 
   span_end(s, stream, &sp);
 
   if (use_fused(s)) {
+    // With exit tolerances enabled problems stop after different numbers of iterations, and a wave lives as long
+    // as its slowest problem (closed loop, measured: 4.3 iterations per problem, 7.7 per wave of 16).  The kernel
+    // is restartable -- all solver state is in the workspace between launches -- so it runs in stages and the
+    // problems still iterating are compacted into dense waves in between.  Results are bitwise those of a single
+    // launch: a problem's arithmetic does not depend on the lanes it occupies.
+    const int total = (int)s->params.max_iterations;
+    const bool exits = s->params.relative_exit_tol > 0.0 || s->params.absolute_first_derivative_tol > 0.0;
+    bool staged = exits && s->stage_first > 0 && s->stage_next > 0 && total > s->stage_first;
+    // a batch that fits the machine in one round of resident waves (2 per SIMD) ends with its slowest wave either
+    // way: staging would only add launches
+    if (s->stage_auto && (B * (int64_t)(s->S - 1) + 63) / 64 <= 2048) staged = false;
+    if (staged && s->active == nullptr &&
+        hipMalloc((void**)&s->active, ((size_t)s->cap + 1) * sizeof(int32_t)) != hipSuccess) {
+      s->active = nullptr;
+      staged = false;  // out of memory for the index list: fall back to the single launch (same results)
+    }
+    a.active_list = nullptr;
+    a.active_count = nullptr;
     span_begin(s, CPMPC_KERNEL_FUSED, stream, &sp);
-    launch_fused<R, M>(a, s->S - 1, s->SP, (int)s->params.max_iterations, stream);
+    launch_fused<R, M>(a, s->S - 1, s->SP, staged ? s->stage_first : total, stream);
     span_end(s, stream, &sp);
+    for (int done = s->stage_first; staged && done < total; done += s->stage_next) {
+      int32_t* count = s->active + s->cap;
+      span_begin(s, CPMPC_KERNEL_FUSED, stream, &sp);
+      HIP_TRY(hipMemsetAsync(count, 0, sizeof(int32_t), stream));
+      hipLaunchKernelGGL(compact_active_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, stream,
+                         (const int32_t*)(s->ist + (size_t)IS_STATUS * (size_t)s->cap), B, s->active, count);
+      a.active_list = s->active;
+      a.active_count = count;
+      const int k = (total - done < s->stage_next) ? (total - done) : s->stage_next;
+      launch_fused<R, M>(a, s->S - 1, s->SP, k, stream);
+      span_end(s, stream, &sp);
+    }
   } else {
     for (int it = 0; it < (int)s->params.max_iterations; ++it) {
       span_begin(s, CPMPC_KERNEL_LINEARIZE, stream, &sp);

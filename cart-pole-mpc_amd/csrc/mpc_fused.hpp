@@ -165,8 +165,16 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
   const int s = lane % L;            // my shooting interval
   const int gbase = lane - s;        // first lane of my group
   int64_t pp = (int64_t)blockIdx.x * PPW + lane / L;
-  const bool valid = pp < a.B;
-  if (!valid) pp = a.B - 1;          // compute redundantly, never store: keeps the shuffles well defined
+  bool valid;
+  if (a.active_list != nullptr) {    // a later stage: my problem comes from the compacted list of active ones
+    const int64_t n_active = *a.active_count;
+    if ((int64_t)blockIdx.x * PPW >= n_active) return;  // block-uniform: nothing left for this wave
+    valid = pp < n_active;
+    pp = a.active_list[valid ? pp : n_active - 1];
+  } else {
+    valid = pp < a.B;
+    if (!valid) pp = a.B - 1;        // compute redundantly, never store: keeps the shuffles well defined
+  }
   const unsigned p = (unsigned)pp;
   const int64_t st = a.stride;
   const int N = a.N;

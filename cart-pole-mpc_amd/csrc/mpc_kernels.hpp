@@ -143,6 +143,9 @@ struct SolverArgs {
   const R* dyn;        // [NP] per-problem, or nullptr
   const R* set_point;  // [1] per-problem, or nullptr
   const R* term_w_pp;  // [NX] per-problem terminal weights in state order (negative = equality row), or nullptr
+  // fused pipeline, later stages: the problems still iterating, compacted (nullptr: all problems, identity map)
+  const int32_t* active_list;
+  const int32_t* active_count;
   typename M::Consts consts;  // shared model constants (used when dyn == nullptr)
   // outputs, packed [field][B] (nullable)
   R* u_out;
@@ -198,6 +201,25 @@ __device__ __forceinline__ void wrap_angles(R (&x)[M::NX]) {
 // ------------------------------------------------------------------------------------------------
 // prepare: initial guess.  One thread per problem.
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// Stream compaction between the stages of the fused pipeline: the indices of the problems that are
+// still iterating (status NONE), densely packed, so that the next stage runs full waves instead of
+// waves kept alive by one straggler.  One atomic per wave (ballot + prefix popcount); the order of the
+// list is arbitrary, which is harmless: a problem's arithmetic does not depend on where it sits.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void compact_active_kernel(const int32_t* status, int64_t B, int32_t* list,
+                                                             int32_t* count) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = p < B && status[p] == kTermNone;
+  const unsigned long long mask = __ballot(active);
+  const int lane = threadIdx.x & 63;
+  const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+  int base = 0;
+  if (lane == 0 && mask != 0) base = atomicAdd(count, __popcll(mask));
+  base = __shfl(base, 0);
+  if (active) list[base + rank] = (int32_t)p;
+}
+
 template <typename R, typename M>
 __global__ __launch_bounds__(64) void prepare_kernel(const SolverArgs<R, M> a) {
   constexpr int NX = M::NX;

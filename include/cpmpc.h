@@ -256,6 +256,11 @@ enum {
  * Returns CPMPC_ERR_UNSUPPORTED if FUSED is requested for a configuration it is not built for. */
 enum { CPMPC_PIPELINE_AUTO = 0, CPMPC_PIPELINE_SPLIT = 1, CPMPC_PIPELINE_FUSED = 2 };
 int cpmpc_set_pipeline(cpmpc_solver* s, int mode);
+/* Fused pipeline with exit tolerances enabled: run `first_iterations` SQP iterations on every problem, then
+ * compact the problems that are still iterating into dense waves before every further `next_iterations` (default
+ * 3 and 1, applied to batches larger than one round of resident waves; an explicit call applies to every batch size;
+ * 0 disables and gives the single launch).  A speed setting only: results do not change. */
+int cpmpc_set_compaction(cpmpc_solver* s, int first_iterations, int next_iterations);
 int cpmpc_get_pipeline(const cpmpc_solver* s); /* the one a step will actually use: SPLIT or FUSED */
 
 /* When enabled, every kernel launch of cpmpc_step_batch is bracketed by HIP events on the launch

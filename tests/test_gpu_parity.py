@@ -596,6 +596,12 @@ def test_profiling_counts_launches(pkg):
     prof = opt.profile_read()
     assert prof["prepare_kernel"][1] == 3 and prof["finalize_kernel"][1] == 3
     assert prof["fused_sqp_kernel"][1] == 3 and prof["linearize_kernel"][1] == 0   # auto -> fused here
+    opt.set_compaction(3, 2)                     # explicit staging: 3 + 2 iterations = two launches per step
+    opt.profile_reset()
+    for _ in range(3):
+        opt.step(T(random_states(rng, B), torch.float32), DYN_UI, 0.0)
+    assert opt.profile_read()["fused_sqp_kernel"][1] == 6
+    opt.set_compaction(0, 0)
     opt.set_pipeline("split")
     opt.profile_reset()
     for _ in range(3):
@@ -692,6 +698,37 @@ def test_fused_and_split_pipelines_agree(pkg, orc, over, dtype):
         assert same.float().mean().item() > 0.75
         d1 = (a[0] - b[0]).abs().max(dim=0).values[same]
         assert d1.median().item() < 1e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_staged_fused_pipeline_is_bitwise_the_single_launch(pkg, dtype):
+    """With exit tolerances enabled the fused pipeline runs in stages and compacts the still-active problems in
+    between (cpmpc_set_compaction).  The kernel restarts from workspace state only and a problem's arithmetic does
+    not depend on its lanes, so every staging gives bitwise the single launch's results -- cold and warm."""
+    rng = np.random.default_rng(44)
+    B = 5000                                     # ragged: not a multiple of 16 or 64
+    x0 = random_states(rng, B)
+    x0[1, ::3] = np.pi / 2 + rng.uniform(-0.3, 0.3, x0[1, ::3].shape)   # a third converge early, the rest late
+    over = dict(max_iterations=8)
+    ref = None
+    for first, nxt in ((0, 0), (3, 2), (1, 1), (2, 5), (7, 1)):
+        opt = pkg.BatchOptimization(pkg.default_params(**over), max_batch=B, dtype=dtype, device=0)
+        opt.set_compaction(first, nxt)
+        sim = pkg.BatchSimulator(B, dtype=dtype, device=0)
+        sim.set_state(T(x0, dtype))
+        res = []
+        for tick in range(3):                    # tick 0 cold, then warm starts
+            o = opt.step(sim.get_state(), DYN_UI, 0.0, want_stats=True, out=pkg.BatchOutputs())
+            res.append((o.u.clone(), o.status.clone(), o.iterations.clone(), o.ls_evals.clone(), o.final_cost.clone()))
+            sim.step(DYN_UI, 0.01, o.u[0].contiguous())
+        if ref is None:
+            ref = res
+            its = N_(res[0][2])
+            assert its.min() < its.max(), "the test needs lanes that stop at different iterations"
+            continue
+        for got, want in zip(res, ref):
+            for g, w in zip(got, want):
+                assert torch.equal(g, w), (first, nxt)
 
 
 def test_two_handles_on_two_streams(pkg):
