@@ -425,6 +425,7 @@ static void fill_args(const cpmpc_solver* s, int64_t B, SolverArgs<R, M>& a) {
   a.N = s->N;
   a.S = s->S;
   a.SP = s->SP;
+  a.iter_cap = (int)p.max_iterations;
   a.dt = (R)p.control_dt;
   // rows exist only for strictly positive weights (optimization.cc:270,296)
   a.wu = (R)(p.u_cost_weight > 0.0 ? p.u_cost_weight : 0.0);
@@ -625,6 +626,8 @@ static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* 
     }
     a.active_list = nullptr;
     a.active_count = nullptr;
+    a.iter_cap = total;
+    a.run_out_below = (int64_t)2048 * (64 / (s->S - 1));  // problems in one round of resident waves (2 per SIMD)
     span_begin(s, CPMPC_KERNEL_FUSED, stream, &sp);
     launch_fused<R, M>(a, s->S - 1, s->SP, staged ? s->stage_first : total, stream);
     span_end(s, stream, &sp);
@@ -633,7 +636,8 @@ static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* 
       span_begin(s, CPMPC_KERNEL_FUSED, stream, &sp);
       HIP_TRY(hipMemsetAsync(count, 0, sizeof(int32_t), stream));
       hipLaunchKernelGGL(compact_active_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, stream,
-                         (const int32_t*)(s->ist + (size_t)IS_STATUS * (size_t)s->cap), B, s->active, count);
+                         (const int32_t*)(s->ist + (size_t)IS_STATUS * (size_t)s->cap),
+                         (const int32_t*)(s->ist + (size_t)IS_ITERS * (size_t)s->cap), total, B, s->active, count);
       a.active_list = s->active;
       a.active_count = count;
       const int k = (total - done < s->stage_next) ? (total - done) : s->stage_next;

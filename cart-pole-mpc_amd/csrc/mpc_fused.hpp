@@ -166,11 +166,15 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
   const int gbase = lane - s;        // first lane of my group
   int64_t pp = (int64_t)blockIdx.x * PPW + lane / L;
   bool valid;
+  int budget = max_iters;            // SQP iterations of this launch
   if (a.active_list != nullptr) {    // a later stage: my problem comes from the compacted list of active ones
     const int64_t n_active = *a.active_count;
     if ((int64_t)blockIdx.x * PPW >= n_active) return;  // block-uniform: nothing left for this wave
     valid = pp < n_active;
     pp = a.active_list[valid ? pp : n_active - 1];
+    // once the active set fits one round of resident waves, further compaction cannot shorten anything: finish
+    // here (every problem stops at its own iteration cap), the stages still to come find an empty list
+    if (n_active <= a.run_out_below) budget = a.iter_cap;
   } else {
     valid = pp < a.B;
     if (!valid) pp = a.B - 1;        // compute redundantly, never store: keeps the shuffles well defined
@@ -206,9 +210,9 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
 #pragma unroll
   for (int i = 0; i < SP; ++i) lds_u[i * 64 + lane] = a.zu[(int64_t)(s * SP + i) * st + p];
 
-  for (int it = 0; it < max_iters; ++it) {
-    if (!__any(status == kTermNone)) break;
-    const bool live = (status == kTermNone);
+  for (int it = 0; it < budget; ++it) {
+    const bool live = (status == kTermNone) && (iters < a.iter_cap);  // frozen once terminated or at max_iterations
+    if (!__any(live)) break;
 
     CPMPC_TICK(7);
     // ================= linearise my interval (optimization.cc:99-160) ==================================

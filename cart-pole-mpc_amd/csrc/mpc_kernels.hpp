@@ -146,6 +146,8 @@ struct SolverArgs {
   // fused pipeline, later stages: the problems still iterating, compacted (nullptr: all problems, identity map)
   const int32_t* active_list;
   const int32_t* active_count;
+  int iter_cap;            // max_iterations: a problem never iterates past it, however the launches are staged
+  int64_t run_out_below;   // a later stage with at most this many active problems runs them to the end
   typename M::Consts consts;  // shared model constants (used when dyn == nullptr)
   // outputs, packed [field][B] (nullable)
   R* u_out;
@@ -207,10 +209,10 @@ __device__ __forceinline__ void wrap_angles(R (&x)[M::NX]) {
 // waves kept alive by one straggler.  One atomic per wave (ballot + prefix popcount); the order of the
 // list is arbitrary, which is harmless: a problem's arithmetic does not depend on where it sits.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void compact_active_kernel(const int32_t* status, int64_t B, int32_t* list,
-                                                             int32_t* count) {
+__global__ __launch_bounds__(256) void compact_active_kernel(const int32_t* status, const int32_t* iters,
+                                                             int iter_cap, int64_t B, int32_t* list, int32_t* count) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool active = p < B && status[p] == kTermNone;
+  const bool active = p < B && status[p] == kTermNone && iters[p] < iter_cap;
   const unsigned long long mask = __ballot(active);
   const int lane = threadIdx.x & 63;
   const int rank = __popcll(mask & ((1ull << lane) - 1ull));
