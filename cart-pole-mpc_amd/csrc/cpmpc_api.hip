@@ -193,7 +193,7 @@ struct cpmpc_solver {
   // staged fused pipeline (compaction of the still-active problems between stages); 0/0 = single launch
   int stage_first = 3, stage_next = 1;
   bool stage_auto = true;  // default: stage only batches larger than one round of resident waves
-  int32_t* active = nullptr;  // [cap] compacted problem indices, then one counter
+  int32_t* active = nullptr;  // [cap] compacted problem indices, then two counters
 };
 
 // 2: a register-resident linearisation is compiled for this spacing; 1: served by the generic kernel
@@ -620,7 +620,7 @@ static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* 
     // way: staging would only add launches
     if (s->stage_auto && (B * (int64_t)(s->S - 1) + 63) / 64 <= 2048) staged = false;
     if (staged && s->active == nullptr &&
-        hipMalloc((void**)&s->active, ((size_t)s->cap + 1) * sizeof(int32_t)) != hipSuccess) {
+        hipMalloc((void**)&s->active, ((size_t)s->cap + 2) * sizeof(int32_t)) != hipSuccess) {
       s->active = nullptr;
       staged = false;  // out of memory for the index list: fall back to the single launch (same results)
     }
@@ -631,8 +631,12 @@ static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* 
     span_begin(s, CPMPC_KERNEL_FUSED, stream, &sp);
     launch_fused<R, M>(a, s->S - 1, s->SP, staged ? s->stage_first : total, stream);
     span_end(s, stream, &sp);
-    for (int done = s->stage_first; staged && done < total; done += s->stage_next) {
-      int32_t* count = s->active + s->cap;
+    int stage = 0;
+    for (int done = s->stage_first; staged && done < total; done += s->stage_next, ++stage) {
+      int32_t* count = s->active + s->cap + (stage & 1);       // two counters: this compaction and the one before
+      a.prev_count = stage ? s->active + s->cap + ((stage - 1) & 1) : nullptr;
+      a.prev_total = B;
+      a.remaining = total - done;
       span_begin(s, CPMPC_KERNEL_FUSED, stream, &sp);
       HIP_TRY(hipMemsetAsync(count, 0, sizeof(int32_t), stream));
       hipLaunchKernelGGL(compact_active_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, stream,

@@ -175,6 +175,10 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
     // once the active set fits one round of resident waves, further compaction cannot shorten anything: finish
     // here (every problem stops at its own iteration cap), the stages still to come find an empty list
     if (n_active <= a.run_out_below) budget = a.iter_cap;
+    // likewise when hardly anybody has stopped since the previous compaction and little is left to run (a cold
+    // start with few iterations): another stage would cost a launch and buy nothing
+    const int64_t n_prev = a.prev_count ? (int64_t)*a.prev_count : a.prev_total;
+    if (n_active * 10 >= n_prev * 9 && a.remaining <= 2 * max_iters) budget = a.iter_cap;
   } else {
     valid = pp < a.B;
     if (!valid) pp = a.B - 1;        // compute redundantly, never store: keeps the shuffles well defined

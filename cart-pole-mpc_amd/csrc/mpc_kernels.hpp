@@ -148,6 +148,9 @@ struct SolverArgs {
   const int32_t* active_count;
   int iter_cap;            // max_iterations: a problem never iterates past it, however the launches are staged
   int64_t run_out_below;   // a later stage with at most this many active problems runs them to the end
+  const int32_t* prev_count;  // active problems at the previous compaction (nullptr: prev_total)
+  int64_t prev_total;
+  int remaining;           // iterations still to run, this stage included
   typename M::Consts consts;  // shared model constants (used when dyn == nullptr)
   // outputs, packed [field][B] (nullable)
   R* u_out;
