@@ -120,6 +120,25 @@ def variants(pkg, args, tdt, dev, local_rank, x0, B):
         res.setdefault("step_length_memory", {})[name] = {
             "re-plans/s": B / dt, "mean_merit_evals_per_iter": float(o.ls_evals.float().mean().item() / args.iters),
             "median_final_eq_l1": float(o.final_eq_l1.median().item()), "median_final_cost": float(o.final_cost.median().item())}
+    # (1c) the parity dtype: the workload of the timed region in fp64 at a quarter of the batch
+    if tdt == torch.float32:
+        B64 = max(B // 4, 1)
+        o64 = pkg.BatchOptimization(pa, max_batch=B64, dtype=torch.float64, device=local_rank)
+        o64.set_pipeline(args.pipeline)
+        x64 = x0[:, :B64].double().contiguous()
+        out64 = pkg.BatchOutputs()
+        for _ in range(2):
+            o64.reset()
+            o64.step(x64, DYN_UI, 0.0, want_predicted=True, want_stats=True, out=out64)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            o64.reset()
+            o64.step(x64, DYN_UI, 0.0, want_predicted=True, want_stats=True, out=out64)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        res["fp64"] = {"re-plans/s": B64 / dt, "ms_per_step": dt * 1e3, "batch": B64, "pipeline": o64.pipeline()}
+        del o64, out64, x64
     # closed loop from near-upright states: re-plan (warm after the first tick) -> apply u_0 -> plant step
     ticks = 50
     rng = np.random.default_rng(7)
