@@ -604,7 +604,7 @@ static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* 
   ProfSpan sp;
 
   span_begin(s, CPMPC_KERNEL_PREPARE, stream, &sp);
-  hipLaunchKernelGGL((prepare_kernel<R, M>), gridB, dim3(64), 0, stream, a);
+  hipLaunchKernelGGL((prepare_kernel<R, M>), dim3((unsigned)((B + 255) / 256)), dim3(256), 0, stream, a);
   span_end(s, stream, &sp);
 
   if (use_fused(s)) {

@@ -226,9 +226,9 @@ __global__ __launch_bounds__(256) void compact_active_kernel(const int32_t* stat
 }
 
 template <typename R, typename M>
-__global__ __launch_bounds__(64) void prepare_kernel(const SolverArgs<R, M> a) {
+__global__ __launch_bounds__(256) void prepare_kernel(const SolverArgs<R, M> a) {  // 256-thread workgroups, as finalize
   constexpr int NX = M::NX;
-  const unsigned p = blockIdx.x * 64u + threadIdx.x;
+  const unsigned p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= a.B) return;
   const int64_t st = a.stride;
   const typename M::Consts k = load_consts(a, p);
