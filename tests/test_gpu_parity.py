@@ -731,6 +731,30 @@ def test_staged_fused_pipeline_is_bitwise_the_single_launch(pkg, dtype):
                 assert torch.equal(g, w), (first, nxt)
 
 
+def test_staging_engages_by_itself_on_large_batches(pkg):
+    """Default settings: a batch larger than one round of resident waves is staged automatically when exit tolerances
+    are enabled (more than one fused launch per step), a small one is not; the results are the single launch's."""
+    rng = np.random.default_rng(45)
+    B = 40000
+    x0 = random_states(rng, B)
+    x0[1, ::2] = np.pi / 2 + rng.uniform(-0.3, 0.3, B // 2)
+    auto = pkg.BatchOptimization(pkg.default_params(), max_batch=B, dtype=torch.float32, device=0)
+    auto.profile_enable(True)
+    a = auto.step(T(x0, torch.float32), DYN_UI, 0.0, want_stats=True)
+    assert auto.profile_read()["fused_sqp_kernel"][1] > 1
+    single = pkg.BatchOptimization(pkg.default_params(), max_batch=B, dtype=torch.float32, device=0)
+    single.set_compaction(0, 0)
+    single.profile_enable(True)
+    b = single.step(T(x0, torch.float32), DYN_UI, 0.0, want_stats=True)
+    assert single.profile_read()["fused_sqp_kernel"][1] == 1
+    assert torch.equal(a.u, b.u) and torch.equal(a.status, b.status) and torch.equal(a.iterations, b.iterations)
+    assert len(set(N_(a.iterations).tolist())) > 3
+    small = pkg.BatchOptimization(pkg.default_params(), max_batch=512, dtype=torch.float32, device=0)
+    small.profile_enable(True)
+    small.step(T(x0[:, :512], torch.float32), DYN_UI, 0.0)
+    assert small.profile_read()["fused_sqp_kernel"][1] == 1
+
+
 def test_two_handles_on_two_streams(pkg):
     """Handles are independent: two solvers stepping concurrently on two HIP streams give bitwise the results
     they give one after the other (every launch of a step goes to the caller's current stream)."""
