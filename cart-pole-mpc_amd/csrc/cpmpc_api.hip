@@ -516,7 +516,8 @@ static bool fused_built(int model, int L, int SP) {
   (void)model;
   return (L == 4 && SP == 10) || (L == 8 && SP == 5) || (L == 2 && SP == 10) || (L == 4 && SP == 5) ||
          (L == 8 && SP == 10) || (L == 16 && SP == 10) || (L == 16 && SP == 5) ||  // horizons of 80 and 160 steps
-         (L == 2 && SP == 20);
+         (L == 2 && SP == 20) ||
+         (L == 5 && SP == 8) || (L == 10 && SP == 4) || (L == 5 && SP == 4);  // groups that straddle DPP rows
 }
 static bool use_fused(const cpmpc_solver* s) {
   if (s->pipeline == CPMPC_PIPELINE_SPLIT) return false;
@@ -552,6 +553,9 @@ static void launch_fused(const SolverArgs<R, M>& a, int L, int SP, int max_iters
     CPMPC_FUSED(16, 10)
     CPMPC_FUSED(16, 5)
     CPMPC_FUSED(2, 20)
+    CPMPC_FUSED(5, 8)
+    CPMPC_FUSED(10, 4)
+    CPMPC_FUSED(5, 4)
 #undef CPMPC_FUSED
   }
 }

@@ -78,7 +78,8 @@ constexpr int kDppQuadXor2 = 2 | (3 << 2) | (0 << 4) | (1 << 6);  // quad_perm:[
 constexpr int kDppRowShl1 = 0x101;                                // lane i reads lane i+1 (inside its row)
 constexpr int kDppRowShr1 = 0x111;                                // lane i reads lane i-1 (inside its row)
 
-// sum over the group, bitwise identical in all its lanes (commutative butterfly)
+// sum over the group, bitwise identical in all its lanes: a commutative butterfly when L is a power of two, else
+// (groups of 5, 10, ... lanes) every lane adds the group's values in the same fixed order
 template <typename R, int L>
 __device__ __forceinline__ R group_sum(R v) {
   if constexpr (L == 4) {
@@ -86,20 +87,29 @@ __device__ __forceinline__ R group_sum(R v) {
     v += dpp<kDppQuadXor2>(v);
   } else if constexpr (L == 2) {
     v += dpp<kDppQuadXor1>(v);
-  } else {
+  } else if constexpr ((L & (L - 1)) == 0) {
 #pragma unroll
     for (int off = 1; off < L; off <<= 1) v += __shfl_xor(v, off);
+  } else {
+    const int gb = (int)threadIdx.x - (int)threadIdx.x % L;
+    R acc = __shfl(v, gb);
+#pragma unroll
+    for (int j = 1; j < L; ++j) acc += __shfl(v, gb + j);
+    v = acc;
   }
   return v;
 }
-// value of my right / left neighbour lane; callers discard it at the group edge
-template <typename R>
+// value of my right / left neighbour lane; callers discard it at the group edge.  Groups whose size divides 16
+// never straddle a DPP row; the others go through the wave shuffle.
+template <typename R, int L>
 __device__ __forceinline__ R lane_right(R v) {
-  return dpp<kDppRowShl1>(v);
+  if constexpr (16 % L == 0) return dpp<kDppRowShl1>(v);
+  else return __shfl(v, (int)threadIdx.x + 1);
 }
-template <typename R>
+template <typename R, int L>
 __device__ __forceinline__ R lane_left(R v) {
-  return dpp<kDppRowShr1>(v);
+  if constexpr (16 % L == 0) return dpp<kDppRowShr1>(v);
+  else return __shfl(v, (int)threadIdx.x - 1);
 }
 // value held by the first / last lane of my group
 template <typename R, int L>
@@ -165,12 +175,14 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
   const int s = lane % L;            // my shooting interval
   const int gbase = lane - s;        // first lane of my group
   int64_t pp = (int64_t)blockIdx.x * PPW + lane / L;
+  const bool in_group = lane / L < PPW;  // 64 % L lanes at the end of the wave hold no whole group: they ride along
+  if (!in_group) pp = (int64_t)blockIdx.x * PPW;
   bool valid;
   int budget = max_iters;            // SQP iterations of this launch
   if (a.active_list != nullptr) {    // a later stage: my problem comes from the compacted list of active ones
     const int64_t n_active = *a.active_count;
     if ((int64_t)blockIdx.x * PPW >= n_active) return;  // block-uniform: nothing left for this wave
-    valid = pp < n_active;
+    valid = in_group && pp < n_active;
     pp = a.active_list[valid ? pp : n_active - 1];
     // once the active set fits one round of resident waves, further compaction cannot shorten anything: finish
     // here (every problem stops at its own iteration cap), the stages still to come find an empty list
@@ -180,8 +192,8 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
     const int64_t n_prev = a.prev_count ? (int64_t)*a.prev_count : a.prev_total;
     if (n_active * 10 >= n_prev * 9 && a.remaining <= 2 * max_iters) budget = a.iter_cap;
   } else {
-    valid = pp < a.B;
-    if (!valid) pp = a.B - 1;        // compute redundantly, never store: keeps the shuffles well defined
+    valid = in_group && pp < a.B;
+    if (pp >= a.B) pp = a.B - 1;     // compute redundantly, never store: keeps the shuffles well defined
   }
   const unsigned p = (unsigned)pp;
   const int64_t st = a.stride;
@@ -194,6 +206,7 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
 
   // ---- per-problem state, replicated in the L lanes of the group -------------------------------------
   int status = a.ist[IS_STATUS * st + p];
+  if (!in_group) status = kTermMaxIterations;  // riding lanes never keep the wave's loops alive (and never store)
   int iters = a.ist[IS_ITERS * st + p], evals_tot = a.ist[IS_LS_EVALS * st + p], failed = a.ist[IS_FAILED * st + p];
   R lam = a.sc[SC_LAMBDA * st + p], mu = a.sc[SC_MU * st + p], a_start = a.sc[SC_ALPHA * st + p];
   R f_last = a.sc[SC_F_LAST * st + p], cn_last = a.sc[SC_CN_LAST * st + p];
@@ -273,9 +286,9 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
     CPMPC_TICK(0);
     // neighbours' boundary controls (u_{k-1} of my first control, u_{k+1} of my last one)
     const R u_first = lds_u[0 * 64 + lane], u_last = lds_u[(SP - 1) * 64 + lane];
-    R u_left = lane_left(u_last);
+    R u_left = lane_left<R, L>(u_last);
     if (s == 0) u_left = u_prev;
-    const R u_right = lane_right(u_first);  // unused for s = L-1
+    const R u_right = lane_right<R, L>(u_first);  // unused for s = L-1
 
     // ================= block-parallel sweeps ===============================================================
     // All three sweeps of the structured QP are linear recurrences in k, so every lane first solves its own
@@ -408,11 +421,11 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
           R wo = e_blk * w_in[r];
 #pragma unroll
           for (int m = 0; m < NX; ++m) wo += Psi[r][m] * wt[m];
-          const R v = lane_right(wo);
+          const R v = lane_right<R, L>(wo);
           w_in[r] = edge ? w_in[r] : v;
         }
         {
-          const R v = lane_right(gwt + e_blk * gw_in);
+          const R v = lane_right<R, L>(gwt + e_blk * gw_in);
           gw_in = edge ? gw_in : v;
         }
         R T[NX][NX];
@@ -429,7 +442,7 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
         for (int r = 0; r < NX; ++r)
 #pragma unroll
           for (int c = 0; c < NX; ++c) {
-            const R v = lane_right(T[r][c]);
+            const R v = lane_right<R, L>(T[r][c]);
             Psi[r][c] = edge ? Psi[r][c] : v;
           }
       }
@@ -626,10 +639,10 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, co
           const bool edge = (s == 0);
 #pragma unroll
           for (int t = 0; t < NX; ++t) {
-            const R v = lane_left(dxe[t]);
+            const R v = lane_left<R, L>(dxe[t]);
             dxs[t] = edge ? dxs[t] : v;
           }
-          const R v1 = lane_left(dut + et * du_in);
+          const R v1 = lane_left<R, L>(dut + et * du_in);
           du_in = edge ? du_in : v1;
         }
       }

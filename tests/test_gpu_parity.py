@@ -660,6 +660,32 @@ def test_long_horizon_fp32_stays_finite(pkg):
         assert (out.status == pkg.capi.TERM["MAX_ITERATIONS"]).float().mean().item() > 0.5
 
 
+@pytest.mark.parametrize("over", [dict(state_spacing=8, max_iterations=5), dict(state_spacing=4, max_iterations=4),
+                                  dict(window_length=20, state_spacing=4, max_iterations=5)])
+def test_fused_with_groups_that_straddle_dpp_rows(pkg, orc, over):
+    """5 or 10 intervals per problem: groups of lanes that do not divide a 16-lane DPP row (wave shuffles, ordered
+    group sums, 4 riding lanes per wave).  Against the oracle and against the split pipeline; ragged batch."""
+    rng = np.random.default_rng(17)
+    B = 203
+    x0 = random_states(rng, B)
+    x0[1, ::2] = np.pi / 2 + rng.uniform(-0.4, 0.4, x0[1, ::2].shape)
+    opt = pkg.BatchOptimization(pkg.default_params(**over), max_batch=B, dtype=torch.float64, device=0)
+    assert opt.pipeline() == "fused"
+    out = opt.step(T(x0), DYN_UI, 0.0, want_stats=True)
+    u_cpu, _, st_cpu, it_cpu, _ = orc.step_batch_cold(orc.default_opt_params(**over), DYN_UI, 0.0, x0)
+    ok = (N_(out.status) == st_cpu) & (N_(out.iterations) == it_cpu)
+    assert ok.mean() > 0.97
+    err = np.abs(N_(out.u) - u_cpu).max(axis=0)
+    assert (err[ok] < 1e-5).mean() >= 0.98 and np.median(err[ok]) < 1e-8
+    opt.set_pipeline("split")
+    opt.reset()
+    out2 = opt.step(T(x0), DYN_UI, 0.0, want_stats=True)
+    same = N_(out2.status) == N_(out.status)
+    assert same.mean() > 0.97
+    assert (np.abs(N_(out2.u) - N_(out.u)).max(axis=0)[same] < 1e-6).mean() > 0.97
+    assert torch.equal(out2.ls_evals[T(same, torch.bool)], out.ls_evals[T(same, torch.bool)])
+
+
 @pytest.mark.parametrize("over", [dict(NO_TOL), dict(), dict(state_spacing=5, max_iterations=6),
                                   dict(window_length=20, max_iterations=6),
                                   dict(window_length=20, state_spacing=5, max_iterations=6)])
@@ -784,8 +810,8 @@ def test_pipeline_selection(pkg):
     assert opt.pipeline() == "fused"                   # (S-1, state_spacing) = (4, 10) is built
     opt.set_pipeline("split")
     assert opt.pipeline() == "split"
-    opt2 = pkg.BatchOptimization(pkg.default_params(state_spacing=8), max_batch=64, dtype=torch.float32, device=0)
-    assert opt2.pipeline() == "split"                  # 5 intervals do not divide a 16-lane DPP row: not built
+    opt2 = pkg.BatchOptimization(pkg.default_params(state_spacing=2), max_batch=64, dtype=torch.float32, device=0)
+    assert opt2.pipeline() == "split"                  # 20 intervals of 2 steps: not built
     with pytest.raises(pkg.CpmpcError) as ei:
         opt2.set_pipeline("fused")
     assert ei.value.code == pkg.capi.ERR_UNSUPPORTED
