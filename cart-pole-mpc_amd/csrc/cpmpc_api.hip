@@ -539,10 +539,13 @@ static void launch_fused(const SolverArgs<R, M>& a, int L, int SP, int max_iters
     const dim3 grid((unsigned)((a.B + ppw - 1) / ppw));
 #define CPMPC_FUSED(LV, SPV)                                                                                \
   if (L == LV && SP == SPV) {                                                                               \
-    if (a.dyn == nullptr && sizeof(R) == 4)                                                                 \
-      hipLaunchKernelGGL((fused_sqp_kernel<R, M, SPV, LV, true>), grid, dim3(64), 0, stream, a, max_iters);  \
-    else                                                                                                    \
-      hipLaunchKernelGGL((fused_sqp_kernel<R, M, SPV, LV, false>), grid, dim3(64), 0, stream, a, max_iters); \
+    if constexpr (sizeof(R) == 4) {                                                                         \
+      if (a.dyn == nullptr) {                                                                               \
+        hipLaunchKernelGGL((fused_sqp_kernel<R, M, SPV, LV, true>), grid, dim3(64), 0, stream, a, max_iters); \
+        return;                                                                                             \
+      }                                                                                                     \
+    }                                                                                                       \
+    hipLaunchKernelGGL((fused_sqp_kernel<R, M, SPV, LV, false>), grid, dim3(64), 0, stream, a, max_iters);  \
     return;                                                                                                 \
   }
     CPMPC_FUSED(4, 10)
