@@ -16,7 +16,7 @@ SOURCES = [os.path.join(CSRC, "cpmpc_api.hip")]
 
 def _deps():
     """Every file the library is compiled from: all of csrc/, the public header and this recipe (flags)."""
-    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp", ".h"))]
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp", ".h", ".inc"))]
     return files + [os.path.join(HERE, "..", "include", "cpmpc.h"), os.path.abspath(__file__)]
 
 

@@ -511,17 +511,28 @@ static void launch_linearize(const SolverArgs<R, M>& a, int SP, const XV<R, M::N
 #undef CPMPC_LIN
 }
 
-// fused pipeline: built for both models and these (L = S-1, SP) pairs
-static bool fused_built(int model, int L, int SP) {
-  (void)model;
+// fused pipeline: compiled specialisations for these (L = S-1, SP) pairs ...
+static bool fused_static(int L, int SP) {
   return (L == 4 && SP == 10) || (L == 8 && SP == 5) || (L == 2 && SP == 10) || (L == 4 && SP == 5) ||
          (L == 8 && SP == 10) || (L == 16 && SP == 10) || (L == 16 && SP == 5) ||  // horizons of 80 and 160 steps
          (L == 2 && SP == 20) ||
          (L == 5 && SP == 8) || (L == 10 && SP == 4) || (L == 5 && SP == 4);  // groups that straddle DPP rows
 }
+// ... and a run-time-spacing variant (dynamic LDS) for any other spacing with one of these interval counts whose
+// per-wave LDS (80 scalars per lane and control for NX = 4) fits the 64 KB a dynamic allocation may take
+static size_t fused_dyn_bytes(const cpmpc_solver* s) {
+  const size_t xw = s->NX > 4 ? 8 : 4;
+  return (size_t)s->SP * 64 * (4 + xw) * s->esize;
+}
+static bool fused_dynamic(const cpmpc_solver* s) {
+  const int L = s->S - 1;
+  const bool l_ok = L == 2 || L == 4 || L == 5 || L == 8 || L == 10 || L == 16;
+  return l_ok && fused_dyn_bytes(s) <= 65536;
+}
+static bool fused_built(const cpmpc_solver* s) { return fused_static(s->S - 1, s->SP) || fused_dynamic(s); }
 static bool use_fused(const cpmpc_solver* s) {
   if (s->pipeline == CPMPC_PIPELINE_SPLIT) return false;
-  if (!fused_built(s->model, s->S - 1, s->SP)) return false;
+  if (!fused_built(s)) return false;
   // AUTO: the 6-state model in fp64 needs 61 KB of LDS per wave in the fused kernel (2 waves per CU); the split
   // pipeline is as fast there (measured 10.1 vs 9.7 M re-plans/s), so it stays the default for that case
   if (s->pipeline == CPMPC_PIPELINE_AUTO && s->model == CPMPC_MODEL_DOUBLE && s->dtype == CPMPC_F64) return false;
@@ -560,6 +571,26 @@ static void launch_fused(const SolverArgs<R, M>& a, int L, int SP, int max_iters
     CPMPC_FUSED(10, 4)
     CPMPC_FUSED(5, 4)
 #undef CPMPC_FUSED
+    // no specialisation for this spacing: run-time SP, dynamic LDS
+    const size_t lds = fused_dyn_lds_bytes<R, M>(SP);
+#define CPMPC_FUSED_DYN(LV)                                                                                         \
+  if (L == LV) {                                                                                                    \
+    if constexpr (sizeof(R) == 4) {                                                                                 \
+      if (a.dyn == nullptr) {                                                                                       \
+        hipLaunchKernelGGL((fused_sqp_dyn_kernel<R, M, LV, true>), grid, dim3(64), lds, stream, a, max_iters);      \
+        return;                                                                                                     \
+      }                                                                                                             \
+    }                                                                                                               \
+    hipLaunchKernelGGL((fused_sqp_dyn_kernel<R, M, LV, false>), grid, dim3(64), lds, stream, a, max_iters);         \
+    return;                                                                                                         \
+  }
+    CPMPC_FUSED_DYN(2)
+    CPMPC_FUSED_DYN(4)
+    CPMPC_FUSED_DYN(5)
+    CPMPC_FUSED_DYN(8)
+    CPMPC_FUSED_DYN(10)
+    CPMPC_FUSED_DYN(16)
+#undef CPMPC_FUSED_DYN
   }
 }
 
@@ -567,7 +598,7 @@ extern "C" int cpmpc_set_pipeline(cpmpc_solver* s, int mode) {
   if (!s) return fail(CPMPC_ERR_INVALID_ARG, "null solver");
   if (mode != CPMPC_PIPELINE_AUTO && mode != CPMPC_PIPELINE_SPLIT && mode != CPMPC_PIPELINE_FUSED)
     return fail(CPMPC_ERR_INVALID_ARG, "unknown pipeline mode");
-  if (mode == CPMPC_PIPELINE_FUSED && !fused_built(s->model, s->S - 1, s->SP))
+  if (mode == CPMPC_PIPELINE_FUSED && !fused_built(s))
     return fail(CPMPC_ERR_UNSUPPORTED, "the fused pipeline is not built for model %d with S-1 = %d, state_spacing = %d",
                 s->model, s->S - 1, s->SP);
   s->pipeline = mode;

@@ -815,6 +815,13 @@ def test_pipeline_selection(pkg):
     with pytest.raises(pkg.CpmpcError) as ei:
         opt2.set_pipeline("fused")
     assert ei.value.code == pkg.capi.ERR_UNSUPPORTED
+    # spacings without a compiled specialisation run the run-time-spacing fused kernel when the interval count is one
+    # of {2, 4, 5, 8, 10, 16} and the per-wave LDS fits; otherwise the split pipeline
+    for N, sp, want in ((30, 3, "fused"), (30, 6, "fused"), (30, 15, "fused"), (16, 4, "fused"), (8, 1, "fused"),
+                        (21, 7, "split"), (40, 40, "split"), (400, 100, "split")):
+        o = pkg.BatchOptimization(pkg.default_params(window_length=N, state_spacing=sp), max_batch=64,
+                                  dtype=torch.float32, device=0)
+        assert o.pipeline() == want, (N, sp)
     opt3 = pkg.BatchOptimization(pkg.default_params(), max_batch=64, dtype=torch.float32, device=0, model="double")
     assert opt3.pipeline() == "fused"                  # both models are built; fp64 double defaults to split (LDS)
     opt4 = pkg.BatchOptimization(pkg.default_params(), max_batch=64, dtype=torch.float64, device=0, model="double")
