@@ -512,11 +512,9 @@ static void launch_linearize(const SolverArgs<R, M>& a, int SP, const XV<R, M::N
 }
 
 // fused pipeline: compiled specialisations for these (L = S-1, SP) pairs ...
-static bool fused_static(int L, int SP) {
+static bool fused_static(int L, int SP) {  // the default horizon's spacings (N = 40) and N = 20
   return (L == 4 && SP == 10) || (L == 8 && SP == 5) || (L == 2 && SP == 10) || (L == 4 && SP == 5) ||
-         (L == 8 && SP == 10) || (L == 16 && SP == 10) || (L == 16 && SP == 5) ||  // horizons of 80 and 160 steps
-         (L == 2 && SP == 20) ||
-         (L == 5 && SP == 8) || (L == 10 && SP == 4) || (L == 5 && SP == 4);  // groups that straddle DPP rows
+         (L == 2 && SP == 20) || (L == 5 && SP == 8) || (L == 10 && SP == 4);
 }
 // ... and a run-time-spacing variant (dynamic LDS) for any other spacing with one of these interval counts whose
 // per-wave LDS (80 scalars per lane and control for NX = 4) fits the 64 KB a dynamic allocation may take
@@ -563,13 +561,9 @@ static void launch_fused(const SolverArgs<R, M>& a, int L, int SP, int max_iters
     CPMPC_FUSED(8, 5)
     CPMPC_FUSED(2, 10)
     CPMPC_FUSED(4, 5)
-    CPMPC_FUSED(8, 10)
-    CPMPC_FUSED(16, 10)
-    CPMPC_FUSED(16, 5)
     CPMPC_FUSED(2, 20)
     CPMPC_FUSED(5, 8)
     CPMPC_FUSED(10, 4)
-    CPMPC_FUSED(5, 4)
 #undef CPMPC_FUSED
     // no specialisation for this spacing: run-time SP, dynamic LDS
     const size_t lds = fused_dyn_lds_bytes<R, M>(SP);
