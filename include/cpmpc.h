@@ -246,13 +246,13 @@ enum {
   CPMPC_KERNEL_COUNT = 5
 };
 
-/* Two implementations of the SQP iterations, same arithmetic:
+/* Two implementations of the SQP iterations, same algorithm and decisions (results agree to rounding):
  *   CPMPC_PIPELINE_SPLIT  linearize_kernel + qp_ls_kernel per iteration, one problem per lane, the
  *                         sensitivities stream through HBM between the kernels (any configuration);
- *   CPMPC_PIPELINE_FUSED  one launch for all iterations, a problem spread over S-1 lanes, sensitivities in
- *                         registers (built for the single pendulum with (S-1, state_spacing) in
- *                         {(4,10), (8,5), (2,10), (4,5)});
- *   CPMPC_PIPELINE_AUTO   fused where built, else split (default).
+ *   CPMPC_PIPELINE_FUSED  one launch for all iterations, a problem spread over its S-1 shooting intervals' lanes,
+ *                         sensitivities and QP factors in registers and LDS.  Both models; any state_spacing whose
+ *                         interval count S-1 is one of 2, 4, 5, 8, 10, 16 and whose per-wave LDS fits 64 KB;
+ *   CPMPC_PIPELINE_AUTO   fused where built, else split (default; the 6-state model in fp64 stays on split).
  * Returns CPMPC_ERR_UNSUPPORTED if FUSED is requested for a configuration it is not built for. */
 enum { CPMPC_PIPELINE_AUTO = 0, CPMPC_PIPELINE_SPLIT = 1, CPMPC_PIPELINE_FUSED = 2 };
 int cpmpc_set_pipeline(cpmpc_solver* s, int mode);
