@@ -311,10 +311,20 @@ def main():
     st = out.status.cpu().numpy()
     line["status_histogram"] = {pkg.capi.TERM_NAMES[int(c)]: int((st == c).sum()) for c in np.unique(st)}
     line["mean_merit_evals_per_iter"] = float(out.ls_evals.float().mean().item() / args.iters)
+    # the secondary legs must never cost the primary line: a failure in one of them is recorded, not raised
     if world == 1 and not args.no_variants:
-        line["variants"] = variants(pkg, args, tdt, dev, local_rank, x0, B)
+        try:
+            line["variants"] = variants(pkg, args, tdt, dev, local_rank, x0, B)
+        except Exception as exc:  # noqa: BLE001
+            line["variants"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    base = None
     if not args.no_cpu_baseline and world == 1:
-        base, u_cpu, n = cpu_baseline(x0_np, over)
+        try:
+            base, u_cpu, n = cpu_baseline(x0_np, over)
+        except Exception as exc:  # noqa: BLE001
+            line["cpu_baseline"] = {"value": None, "unit": "re-plans/s", "cores": 0, "kind": "port",
+                                    "sample": "failed: %s: %s" % (type(exc).__name__, exc)}
+    if base is not None:
         line["cpu_baseline"] = base
         err = np.abs(out.u[:, :n].double().cpu().numpy() - u_cpu).max(axis=0)
         cl1 = out.final_eq_l1[:n].double().cpu().numpy()
