@@ -6,8 +6,17 @@ independent cart-poles per GPU, horizon N = 40, state_spacing = 10, fp32, cold s
 iterations (exit tolerances disabled so every lane does the full fixed work), seeded random initial
 states, shared dynamics parameters, outputs u [N,B], predicted states
 [N,4,B] and status written.  A "step" = one full batched re-plan (Optimization::Step for every
-problem).  With --gpus N > 1 every rank solves its own 262144 problems (weak scaling, no data-path
-collective) and the control sequences are gathered to rank 0 over RCCL.
+problem).
+
+`--gpus N` (BASELINE.json configs[3] at N = 8): one process per GPU.  Rank r solves problems
+shard_range(N * 262144, r, N) of ONE seeded global batch (weak scaling, no data-path collective) and
+the control sequences are gathered to rank 0 over RCCL.  When WORLD_SIZE is not in the environment
+(plain `python bench.py --gpus N`) this process starts the N ranks itself -- before anything touches
+the GPU -- and relays rank 0's line; under `python -m torch.distributed.run` it is one of the ranks.
+
+The same line also carries the record of the parity dtype (`fp64`: the reference computes in double
+only, optimization/single_pendulum_dynamics.hpp:185): the same workload at the same batch in fp64,
+timed the same way, with its own roofline and its control sequences compared with the CPU oracle.
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task description).
 """
@@ -15,12 +24,12 @@ import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 import numpy as np
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -42,43 +51,232 @@ FLOPS_PER_LAUNCH_UNIT = {
 }
 PEAK_VALU_TFLOPS = {"f32": 157.3, "f64": 78.6}  # MI355X_MICROARCH.md (vector peak); f64 = public spec
 PEAK_HBM_GBPS = 8000.0
+SEED = 1000
 
 
-def synth_states(seed, B):
+# ------------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` with no WORLD_SIZE starts the N ranks (nothing here touches the GPU)
+# ------------------------------------------------------------------------------------------------------------------
+def visible_gpus():
+    import torch
+    return torch.cuda.device_count()   # counts devices without initialising the runtime on this image
+
+
+def rank_environments(n, n_devices, share, port):
+    """Environment of each of the n ranks.  One GPU per rank; with `share` (CPMPC_BENCH_SHARE_DEVICE=1, a
+    rehearsal on a box with fewer GPUs than ranks) ranks wrap around the visible devices."""
+    if n_devices < 1:
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if n > n_devices and not share:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (set CPMPC_BENCH_SHARE_DEVICE=1 to rehearse "
+                         "with several ranks per GPU; the gather then goes through gloo)" % (n, n_devices))
+    envs = []
+    for r in range(n):
+        e = dict(os.environ)
+        e.update({"RANK": str(r), "LOCAL_RANK": str(r % n_devices), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                  "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0",
+                  "CPMPC_BENCH_SPAWNED": "1"})
+        envs.append(e)
+    return envs
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv, n_devices=None, script=None, timeout=None):
+    """Start n fresh rank processes (never a re-exec of a process that has touched the GPU), wait for them and return
+    (exit code, rank 0's stdout).  Rank 0's stdout is captured, the other ranks write to stderr."""
+    share = os.environ.get("CPMPC_BENCH_SHARE_DEVICE", "0") == "1"
+    if n_devices is None:
+        n_devices = visible_gpus()
+    envs = rank_environments(n, n_devices, share, free_port())
+    cmd = [sys.executable, script or os.path.abspath(__file__)] + list(argv)
+    procs = []
+    for r, e in enumerate(envs):
+        procs.append(subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr,
+                                      text=True))
+    out0 = ""
+    rc = 0
+    try:
+        out0, _ = procs[0].communicate(timeout=timeout)
+        for p in procs:
+            p.wait(timeout=timeout)
+            rc = rc or p.returncode
+    finally:
+        for p in procs:   # exactly the processes started here
+            if p.poll() is None:
+                p.kill()
+    return rc, out0
+
+
+def last_json_line(text):
+    for ln in reversed(text.strip().splitlines()):
+        ln = ln.strip()
+        if ln.startswith("{") and ln.endswith("}"):
+            try:
+                json.loads(ln)
+                return ln
+            except ValueError:
+                continue
+    return None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# workload
+# ------------------------------------------------------------------------------------------------------------------
+def synth_states(seed, B, lo=0, hi=None):
+    """Columns [lo, hi) of the seeded global batch of B initial states."""
     rng = np.random.default_rng(seed)
-    return np.stack([rng.uniform(-0.6, 0.6, B), rng.uniform(-np.pi, np.pi, B), rng.uniform(-1, 1, B),
-                     rng.uniform(-3, 3, B)])
+    x = np.stack([rng.uniform(-0.6, 0.6, B), rng.uniform(-np.pi, np.pi, B), rng.uniform(-1, 1, B),
+                  rng.uniform(-3, 3, B)])
+    return np.ascontiguousarray(x[:, lo:(B if hi is None else hi)])
 
 
-def cpu_baseline(x0_np, over, seconds_target=15.0):
+def host_cpu_info():
+    """Threads this process may run on, and what the cgroup grants (the GPU box hands out a share of a large host)."""
+    info = {"os_cpu_count": os.cpu_count()}
+    try:
+        info["affinity"] = len(os.sched_getaffinity(0))
+    except Exception:  # noqa: BLE001
+        info["affinity"] = None
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, per = fh.read().split()
+            if q != "max":
+                quota = float(q) / float(per)
+    except Exception:  # noqa: BLE001
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fh:
+                q = float(fh.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                per = float(fh.read())
+            if q > 0:
+                quota = q / per
+        except Exception:  # noqa: BLE001
+            quota = None
+    info["cgroup_cpu_quota"] = quota
+    usable = info["affinity"] or info["os_cpu_count"] or 1
+    if quota:
+        usable = max(1, min(usable, int(quota + 0.5)))
+    info["usable"] = int(usable)
+    return info
+
+
+def cpu_baseline(x0_np, over, seconds_target=20.0):
     """The oracle (CPU restatement, fp64, OpenMP over problems) timed on this host on a bounded sample
     of the same workload.  Reported baseline only."""
     from oracle import oracle as orc
     p = orc.default_opt_params(**over)
-    cores = os.cpu_count() or 1
-    probe = min(max(2048, 32 * cores), x0_np.shape[1])   # large enough that thread start-up does not bias the rate
+    info = host_cpu_info()
+    threads = info["usable"]
+    probe = min(max(2048, 32 * threads), x0_np.shape[1])   # large enough that thread start-up does not bias the rate
     t0 = time.perf_counter()
-    _, _, _, _, used = orc.step_batch_cold(p, DYN_UI, 0.0, x0_np[:, :probe], num_threads=cores)
+    orc.step_batch_cold(p, DYN_UI, 0.0, x0_np[:, :probe], num_threads=threads)
     rate = probe / max(time.perf_counter() - t0, 1e-6)
     n = int(min(x0_np.shape[1], max(probe, rate * seconds_target)))
     t0 = time.perf_counter()
-    u, _, st, _, used = orc.step_batch_cold(p, DYN_UI, 0.0, x0_np[:, :n], num_threads=cores)
+    u, _, st, _, used = orc.step_batch_cold(p, DYN_UI, 0.0, x0_np[:, :n], num_threads=threads)
     dt = time.perf_counter() - t0
-    n1 = min(128, x0_np.shape[1])
+    n1 = min(256, x0_np.shape[1])
     t1 = time.perf_counter()
     orc.step_batch_cold(p, DYN_UI, 0.0, x0_np[:, :n1], num_threads=1)
     one = n1 / (time.perf_counter() - t1)
     return {"value": n / dt, "unit": "re-plans/s", "cores": int(used), "kind": "port", "one_core_value": one,
+            "parallel_efficiency": (n / dt) / (one * max(int(used), 1)), "host": info,
             "sample": "first %d problems of rank 0's batch, same N=40/5-iteration cold-start workload, fp64, "
-                      "oracle/cpmpc_oracle.c with OpenMP, %.1f s" % (n, dt)}, u, n
+                      "oracle/cpmpc_oracle.c with OpenMP (%d threads), %.1f s" % (n, int(used), dt)}, u, st, n
 
 
-def variants(pkg, args, tdt, dev, local_rank, x0, B):
+def timed_region(torch, dist, sharding, opt, x0, outs, gather, steps, warmup, dev, local_rank, distributed):
+    """W untimed steps, then exactly K steps bracketed by barrier + synchronize on both sides.  Returns
+    (max-over-ranks seconds, per-kernel HIP-event profile of the timed steps, outputs of the last step, its slot)."""
+    state = {"n": 0, "slot": 0}
+
+    def one_step():
+        slot = state["n"] % 2        # output buffers and gather slots advance together, warm-up included
+        state["n"] += 1
+        if gather is not None:
+            gather.wait_slot(slot)   # the buffer we are about to overwrite has been sent
+        opt.reset()                  # cold start: every step is a full re-plan from the sinusoid guess
+        o = opt.step(x0, DYN_UI, 0.0, want_predicted=True, want_stats=True, out=outs[slot])
+        if gather is not None:
+            assert gather.submit(o.u) == slot
+        state["slot"] = slot
+        return o
+
+    def fence():
+        if gather is not None:
+            gather.finish()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    out = None
+    for _ in range(warmup):
+        out = one_step()
+    fence()
+    opt.profile_enable(True)
+    opt.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = one_step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    elapsed = sharding.max_over_ranks(elapsed, dev if dist.is_initialized() and dist.get_backend() == "nccl" else "cpu")
+    prof = opt.profile_read()
+    opt.profile_enable(False)
+    return elapsed, prof, out, state["slot"]
+
+
+def roofline_of(prof, dtype, B, iters, steps, rate_per_gpu):
+    """Roofline object of the dominant kernel (by HIP-event device time over the timed region)."""
+    dom = max(prof, key=lambda k: prof[k][0])
+    dom_ms, dom_n = prof[dom]
+    avg_s = dom_ms / max(dom_n, 1) * 1e-3
+    flops_launch = FLOPS_PER_LAUNCH_UNIT[dom] * B * (iters if dom == "fused_sqp_kernel" else 1)
+    achieved_tf = flops_launch / avg_s / 1e12
+    peak_tf = PEAK_VALU_TFLOPS[dtype]
+    esz = 4 if dtype == "f32" else 8
+    bytes_replan = esz * ((4 + 1) + (60 + 160)) + 4   # read x0 + set-point, write z + predicted, status
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json" if dtype == "f32" else "traffic_latest_%s.json" % dtype)
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("dtype") == dtype and tj.get("batch") == B and dom in tj.get("per_launch_bytes", {}):
+                traffic = tj.get("per_launch_bytes", {}).get(dom)
+        except Exception:  # noqa: BLE001
+            traffic = None
+    return {
+        "bound": "valu", "kernel": dom, "achieved": round(achieved_tf, 3), "peak": peak_tf, "unit": "TFLOP/s",
+        "frac": round(achieved_tf / peak_tf, 4), "traffic": traffic,
+        "traffic_GBps": (round(traffic / avg_s / 1e9, 1) if traffic else None),
+        "traffic_frac_of_hbm_peak": (round(traffic / avg_s / 1e9 / PEAK_HBM_GBPS, 4) if traffic else None),
+        "avg_launch_ms": round(avg_s * 1e3, 4), "launches": int(dom_n),
+        "algorithmic_flops_per_launch": flops_launch,
+        "hbm": {"algorithmic_bytes_per_replan": bytes_replan,
+                "achieved_GBps": round(bytes_replan * rate_per_gpu / 1e9, 3), "peak_GBps": PEAK_HBM_GBPS,
+                "frac": round(bytes_replan * rate_per_gpu / 1e9 / PEAK_HBM_GBPS, 6)},
+        "kernels_ms_per_step": {k: round(v[0] / steps, 4) for k, v in prof.items()},
+        "note": "the path as specified is vector-ALU/transcendental bound (SURVEY.md 8d), neither HBM nor MFMA: "
+                "achieved = SURVEY 8(d) algorithmic flops of the dominant kernel / its HIP-event time vs the "
+                "vector peak. `traffic` = HBM bytes per launch of that kernel from separate rocprofv3 --pmc "
+                "FETCH_SIZE / WRITE_SIZE passes (profiles/traffic_latest*.json)",
+    }
+
+
+def variants(torch, pkg, args, tdt, dev, local_rank, x0, B):
     """Secondary measurements of SURVEY.md 8(d), outside the timed region and never `value`:
     (1) the same cold-start re-plan with the reference's exit tolerances enabled (optimization.hpp:30-34:
         lanes stop at SATISFIED_RELATIVE_TOL / SATISFIED_FIRST_ORDER_TOL; a wave ends with its last lane);
     (2) closed loop: 50 MPC ticks = warm-started re-plan + batched Simulator step (10 RK4 sub-steps), all
-        state resident on the GPU (simulator.cc:11-36, optimization.cc:50-57)."""
+        state resident on the GPU (simulator.cc:11-36, optimization.cc:50-57);
+    (3) one controller at 100 Hz through the C++ facade (viz/src/application.ts:393-399)."""
     res = {}
     p1 = pkg.default_params(max_iterations=args.iters)
     opt = pkg.BatchOptimization(p1, max_batch=B, dtype=tdt, device=local_rank)
@@ -101,44 +299,7 @@ def variants(pkg, args, tdt, dev, local_rank, x0, B):
                             "status_histogram": {pkg.capi.TERM_NAMES[int(c)]: int((st == c).sum()) for c in np.unique(st)},
                             "note": "cold start, max_iterations=%d, relative_exit_tol=1e-5, "
                                     "absolute_first_derivative_tol=1e-6 (reference defaults)" % args.iters}
-    # (1b) the workload of the timed region with the alternative step-length memory ("what would move it
-    #      next"): grow the step only after a first-trial accept.  Faster per iteration, slightly less progress.
-    pa = pkg.default_params(max_iterations=args.iters, relative_exit_tol=0.0, absolute_first_derivative_tol=0.0)
-    for name, so in (("default", None), ("ls_alpha_growth_backtracked=1", pkg.capi.default_solver_opts(ls_alpha_growth_backtracked=1.0))):
-        o2 = pkg.BatchOptimization(pa, max_batch=B, dtype=tdt, device=local_rank, opts=so)
-        o2.set_pipeline(args.pipeline)
-        for _ in range(2):
-            o2.reset()
-            o2.step(x0, DYN_UI, 0.0, want_predicted=True, want_stats=True, out=out)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            o2.reset()
-            o = o2.step(x0, DYN_UI, 0.0, want_predicted=True, want_stats=True, out=out)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / reps
-        res.setdefault("step_length_memory", {})[name] = {
-            "re-plans/s": B / dt, "mean_merit_evals_per_iter": float(o.ls_evals.float().mean().item() / args.iters),
-            "median_final_eq_l1": float(o.final_eq_l1.median().item()), "median_final_cost": float(o.final_cost.median().item())}
-    # (1c) the parity dtype: the workload of the timed region in fp64 at a quarter of the batch
-    if tdt == torch.float32:
-        B64 = max(B // 4, 1)
-        o64 = pkg.BatchOptimization(pa, max_batch=B64, dtype=torch.float64, device=local_rank)
-        o64.set_pipeline(args.pipeline)
-        x64 = x0[:, :B64].double().contiguous()
-        out64 = pkg.BatchOutputs()
-        for _ in range(2):
-            o64.reset()
-            o64.step(x64, DYN_UI, 0.0, want_predicted=True, want_stats=True, out=out64)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            o64.reset()
-            o64.step(x64, DYN_UI, 0.0, want_predicted=True, want_stats=True, out=out64)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / reps
-        res["fp64"] = {"re-plans/s": B64 / dt, "ms_per_step": dt * 1e3, "batch": B64, "pipeline": o64.pipeline()}
-        del o64, out64, x64
+    del opt
     # closed loop from near-upright states: re-plan (warm after the first tick) -> apply u_0 -> plant step
     ticks = 50
     rng = np.random.default_rng(7)
@@ -167,39 +328,79 @@ def variants(pkg, args, tdt, dev, local_rank, x0, B):
                                      "note": "reference defaults (8 iterations max, exits enabled), warm start from the "
                                              "shifted previous solution, plant = 10 RK4 sub-steps per tick, states "
                                              "start within 0.4 rad of upright"}
+    del opt, sim
+    try:
+        res["single_controller_facade"] = single_controller_latency(pkg)
+    except Exception as exc:  # noqa: BLE001
+        res["single_controller_facade"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     return res
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=262144, help="problems per GPU")
-    ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
-    ap.add_argument("--iters", type=int, default=5)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-gather", action="store_true")
-    ap.add_argument("--no-variants", action="store_true", help="skip the secondary measurements (SURVEY 8d)")
-    ap.add_argument("--pipeline", choices=["auto", "split", "fused"], default="auto")
-    args = ap.parse_args()
+def single_controller_latency(pkg):
+    """B = 1 through pypendulum (the reference's real workload: one Optimization::Step + one Simulator::Step per
+    10 ms tick, viz/src/application.ts:393-399), wall time per call in a warm-started closed loop."""
+    pyp = pkg.pypendulum()
+    dyn = pyp.SingleCartPoleParams(*DYN_UI)
+    op = pyp.OptimizationParams()
+    opt = pyp.Optimization(op)
+    sim = pyp.Simulator()
+    zero = pyp.Vector2(0.0, 0.0)
+    t_opt, t_sim = [], []
+    for k in range(60):
+        t0 = time.perf_counter()
+        o = opt.step(sim.get_state(), dyn, 0.0)
+        t1 = time.perf_counter()
+        sim.step(dyn, 0.01, o.u[0], zero, zero)
+        t2 = time.perf_counter()
+        if k >= 10:
+            t_opt.append(t1 - t0)
+            t_sim.append(t2 - t1)
+    return {"Optimization.step_ms_median": float(np.median(t_opt) * 1e3), "Optimization.step_ms_p95": float(np.quantile(t_opt, 0.95) * 1e3),
+            "Simulator.step_ms_median": float(np.median(t_sim) * 1e3), "ticks": len(t_opt),
+            "note": "one controller, reference defaults (N=40, spacing 10, <= 8 iterations, exits enabled), fp64, "
+                    "host buffers in and out, swing-up from hanging"}
+
+
+def parity_stats(u_gpu, u_cpu, st_gpu, st_cpu):
+    err = np.abs(u_gpu - u_cpu).max(axis=0)
+    return {"lanes": int(err.size), "max_abs_du_max": float(err.max()), "max_abs_du_median": float(np.median(err)),
+            "max_abs_du_p99": float(np.quantile(err, 0.99)), "lanes_over_1e-5": int((err > 1e-5).sum()),
+            "status_agree": int((st_gpu == st_cpu).sum())}, err
+
+
+def run_rank(args):
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (python bench.py --gpus N starts "
+                         "them itself; torch.distributed.run must use --nproc-per-node N)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    share = os.environ.get("CPMPC_BENCH_SHARE_DEVICE", "0") == "1"
+    n_dev = torch.cuda.device_count()
+    if local_rank >= n_dev:
+        if not share:
+            raise SystemExit("rank %d: LOCAL_RANK=%d but %d GPU(s) visible" % (rank, local_rank, n_dev))
+        local_rank %= n_dev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # CPMPC_BENCH_FORCE_DIST=1: run the RCCL path (process group, gather, barrier, max-reduce) in a world of one
     force_dist = os.environ.get("CPMPC_BENCH_FORCE_DIST", "0") == "1"
-    if world > 1 or force_dist:
+    distributed = world > 1 or force_dist
+    # RCCL refuses two ranks on one device: a shared-device rehearsal gathers through gloo (host) instead
+    backend = "gloo" if (share and world > n_dev) else "nccl"
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     pkg = importlib.import_module("cart-pole-mpc_amd")
     sharding = importlib.import_module("cart-pole-mpc_amd.sharding")
@@ -209,160 +410,178 @@ def main():
     params = pkg.default_params(**over)
     N = int(params.window_length)
 
-    x0_np = synth_states(1000 + rank, B)  # rank-specific shard of the global synthetic batch
+    total = world * B
+    lo, hi = sharding.shard_range(total, rank, world)    # my contiguous block of the one global batch
+    assert hi - lo == B
+    x0_np = synth_states(SEED, total, lo, hi)
     x0 = torch.tensor(x0_np, dtype=tdt, device=dev)
     opt = pkg.BatchOptimization(params, max_batch=B, dtype=tdt, device=local_rank)
     opt.set_pipeline(args.pipeline)
     outs = [pkg.BatchOutputs(), pkg.BatchOutputs()]
     gather = None
-    if (world > 1 or force_dist) and not args.no_gather:
-        gather = sharding.ResultGather(N, B, tdt, dev, dst=0, depth=2, force=force_dist)
+    if distributed and not args.no_gather:
+        gather = sharding.ResultGather(N, B, tdt, dev, dst=0, depth=2, force=force_dist,
+                                       via_host=(backend == "gloo"))
 
-    state = {"n": 0, "slot": 0}
+    elapsed, prof, out, slot = timed_region(torch, dist, sharding, opt, x0, outs, gather, args.steps, args.warmup, dev,
+                                            local_rank, distributed)
 
-    def one_step(_):
-        slot = state["n"] % 2        # output buffers and gather slots advance together, warm-up included
-        state["n"] += 1
-        if gather is not None:
-            gather.wait_slot(slot)   # the buffer we are about to overwrite has been sent
-        opt.reset()                  # cold start: every step is a full re-plan from the sinusoid guess
-        o = opt.step(x0, DYN_UI, 0.0, want_predicted=True, want_stats=True, out=outs[slot])
-        if gather is not None:
-            assert gather.submit(o.u) == slot
-        state["slot"] = slot
-        return o
-
-    def fence():
-        if gather is not None:
-            gather.finish()
+    # the gather on its own: the same [N, B] block from every rank to rank 0, nothing else in flight
+    gather_ms = None
+    if gather is not None:
+        reps = 5
+        gather.finish()
         torch.cuda.synchronize()
-        if world > 1 or force_dist:
-            dist.barrier(device_ids=[local_rank])
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            s_ = gather.submit(out.u)
+            gather.wait_slot(s_)
         torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        one_step(i)
-    fence()
-    opt.profile_enable(True)
-    opt.profile_reset()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = one_step(i)
-    fence()
-    elapsed = time.perf_counter() - t0
-    elapsed = sharding.max_over_ranks(elapsed, dev)
-    prof = opt.profile_read()
-    opt.profile_enable(False)
+        gather_ms = (time.perf_counter() - t0) / reps * 1e3
 
     if rank != 0:
-        dist.destroy_process_group()
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
         return
 
-    total_problems = world * B
-    value = total_problems * args.steps / elapsed
-    # dominant kernel by measured device time (HIP events on the launch stream, timed region)
-    dom = max(prof, key=lambda k: prof[k][0])
-    dom_ms, dom_n = prof[dom]
-    avg_s = dom_ms / max(dom_n, 1) * 1e-3
-    flops_launch = FLOPS_PER_LAUNCH_UNIT[dom] * B * (args.iters if dom == "fused_sqp_kernel" else 1)
-    achieved_tf = flops_launch / avg_s / 1e12
-    peak_tf = PEAK_VALU_TFLOPS[args.dtype]
-    esz = 4 if args.dtype == "f32" else 8
-    bytes_replan = esz * ((4 + 1) + (60 + 160)) + 4   # read x0 + set-point, write z + predicted, status
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            if tj.get("dtype") == args.dtype and tj.get("batch") == B and dom in tj.get("per_launch_bytes", {}):
-                traffic = tj.get("per_launch_bytes", {}).get(dom)
-        except Exception:
-            traffic = None
-    roofline = {
-        "bound": "valu", "kernel": dom, "achieved": round(achieved_tf, 3), "peak": peak_tf, "unit": "TFLOP/s",
-        "frac": round(achieved_tf / peak_tf, 4), "traffic": traffic,
-        "traffic_GBps": (round(traffic / avg_s / 1e9, 1) if traffic else None),
-        "traffic_frac_of_hbm_peak": (round(traffic / avg_s / 1e9 / PEAK_HBM_GBPS, 4) if traffic else None),
-        "avg_launch_ms": round(avg_s * 1e3, 4), "launches": int(dom_n),
-        "algorithmic_flops_per_launch": flops_launch,
-        "hbm": {"algorithmic_bytes_per_replan": bytes_replan,
-                "achieved_GBps": round(bytes_replan * value / world / 1e9, 3), "peak_GBps": PEAK_HBM_GBPS,
-                "frac": round(bytes_replan * value / world / 1e9 / PEAK_HBM_GBPS, 6)},
-        "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in prof.items()},
-        "note": "the path as specified is vector-ALU/transcendental bound (SURVEY.md 8d), neither HBM nor MFMA: "
-                "achieved = SURVEY 8(d) algorithmic flops of the dominant kernel / its HIP-event time vs the "
-                "vector peak. `traffic` = HBM bytes per launch of that kernel from separate rocprofv3 --pmc "
-                "FETCH_SIZE / WRITE_SIZE passes (profiles/traffic_latest.json); it is the SQP workspace "
-                "(sensitivities, factors, step) streaming between kernels, not compulsory I/O, and "
-                "traffic_frac_of_hbm_peak says how close that streaming runs to the 8 TB/s peak",
-    }
+    value = total * args.steps / elapsed
     line = {
         "metric": "MPC re-plans/sec (whole node), N=40 horizon, 5 SQP iters, batch 256k",
         "value": value, "unit": "re-plans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "BASELINE configs[2]: batch=%d per GPU, N=40, state_spacing=10, %s, cold start, "
+        "config": {"workload": "BASELINE configs[%d]: batch=%d per GPU (%d in total), N=40, state_spacing=10, %s, cold start, "
                                "%d SQP iterations (exits disabled), u+predicted+status written%s"
-                               % (B, args.dtype, args.iters, ", u gathered to rank 0 (RCCL)" if gather else ""),
-                   "batch_per_gpu": B, "horizon": N, "sqp_iterations": args.iters, "pipeline": opt.pipeline(),
-                   "parallelism": "dp%d" % world},
-        "roofline": roofline,
+                               % (2 if world == 1 else 3, B, total, args.dtype, args.iters,
+                                  ", u gathered to rank 0 (%s)" % ("RCCL" if backend == "nccl" else "gloo") if gather else ""),
+                   "batch_per_gpu": B, "global_batch": total, "horizon": N, "sqp_iterations": args.iters,
+                   "pipeline": opt.pipeline(), "parallelism": "dp%d" % world},
+        "roofline": roofline_of(prof, args.dtype, B, args.iters, args.steps, value / world),
     }
-    st = out.status.cpu().numpy()
-    line["status_histogram"] = {pkg.capi.TERM_NAMES[int(c)]: int((st == c).sum()) for c in np.unique(st)}
-    line["mean_merit_evals_per_iter"] = float(out.ls_evals.float().mean().item() / args.iters)
-    # the secondary legs must never cost the primary line: a failure in one of them is recorded, not raised
+    if distributed:
+        line["distributed"] = {"world_size_seen": dist.get_world_size(), "backend": dist.get_backend(),
+                               "spawned_by_bench": os.environ.get("CPMPC_BENCH_SPAWNED", "0") == "1",
+                               "shard_of_rank0": [lo, hi], "gather_ms": gather_ms,
+                               "devices_visible": n_dev}
+    # everything below is secondary: a failure in one leg is recorded, never raised (the primary line must print)
+    try:
+        st = out.status.cpu().numpy()
+        line["status_histogram"] = {pkg.capi.TERM_NAMES[int(c)]: int((st == c).sum()) for c in np.unique(st)}
+        line["mean_merit_evals_per_iter"] = float(out.ls_evals.float().mean().item() / args.iters)
+    except Exception as exc:  # noqa: BLE001
+        line["status_histogram"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    if gather is not None:
+        try:
+            # what rank 0 holds after the last step: the control sequences of all ranks, in global problem order
+            full = gather.assembled(slot)
+            line["gathered"] = {"shape": list(full.shape), "own_block_intact": bool(torch.equal(full[:, :B].to(out.u.device), out.u))}
+            del full
+        except Exception as exc:  # noqa: BLE001
+            line["gathered"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+    u_primary = out.u
+    eq_primary = out.final_eq_l1
+
+    # ---- the parity dtype as a first-class record: same workload, same batch, fp64, timed the same way ----------
+    u64 = st64 = None
+    if world == 1 and args.dtype == "f32" and not args.no_fp64:
+        try:
+            opt64 = pkg.BatchOptimization(params, max_batch=B, dtype=torch.float64, device=local_rank)
+            opt64.set_pipeline(args.pipeline)
+            x64 = torch.tensor(x0_np, dtype=torch.float64, device=dev)
+            outs64 = [pkg.BatchOutputs(), pkg.BatchOutputs()]
+            el64, prof64, o64, _ = timed_region(torch, dist, sharding, opt64, x64, outs64, None, args.steps, args.warmup,
+                                                dev, local_rank, False)
+            v64 = B * args.steps / el64
+            line["fp64"] = {"value": v64, "unit": "re-plans/s", "dtype": "f64", "steps": args.steps, "warmup": args.warmup,
+                            "ms_per_step": el64 / args.steps * 1e3, "batch": B, "pipeline": opt64.pipeline(),
+                            "roofline": roofline_of(prof64, "f64", B, args.iters, args.steps, v64),
+                            "note": "the parity dtype (the reference computes in double only): the workload of the "
+                                    "timed region in fp64 at the same batch, timed the same way"}
+            u64 = o64.u.cpu().numpy()
+            st64 = o64.status.cpu().numpy()
+            del opt64, x64, outs64, o64
+        except Exception as exc:  # noqa: BLE001
+            line["fp64"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     if world == 1 and not args.no_variants:
         try:
-            line["variants"] = variants(pkg, args, tdt, dev, local_rank, x0, B)
+            line["variants"] = variants(torch, pkg, args, tdt, dev, local_rank, x0, B)
         except Exception as exc:  # noqa: BLE001
             line["variants"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
-    base = None
     if not args.no_cpu_baseline and world == 1:
         try:
-            base, u_cpu, n = cpu_baseline(x0_np, over)
+            base, u_cpu, st_cpu, n = cpu_baseline(x0_np, over)
+            line["cpu_baseline"] = base
+            line["gpu_over_cpu"] = value / base["value"]
         except Exception as exc:  # noqa: BLE001
+            base = None
             line["cpu_baseline"] = {"value": None, "unit": "re-plans/s", "cores": 0, "kind": "port",
                                     "sample": "failed: %s: %s" % (type(exc).__name__, exc)}
-    if base is not None:
-        line["cpu_baseline"] = base
-        err = np.abs(out.u[:, :n].double().cpu().numpy() - u_cpu).max(axis=0)
-        cl1 = out.final_eq_l1[:n].double().cpu().numpy()
-        conv = cl1 < 1e-3   # lanes whose shooting defects have closed after the fixed 5 iterations
-        line["parity_sample"] = {"lanes": int(n), "max_abs_du_median": float(np.median(err)),
-                                 "max_abs_du_p99": float(np.quantile(err, 0.99)), "max_abs_du_max": float(err.max()),
-                                 "fraction_within_1e-2": float((err < 1e-2).mean()),
-                                 "converged_lanes": int(conv.sum()),
-                                 "max_abs_du_median_on_converged_lanes": float(np.median(err[conv])) if conv.any() else None,
-                                 "max_abs_du_max_on_converged_lanes": float(err[conv].max()) if conv.any() else None,
-                                 "note": "GPU %s vs fp64 oracle on the cpu_baseline sample; these cold-start swing-up "
-                                         "problems are far from converged after 5 iterations (median |c|_1 %.1f) and the "
-                                         "SQP iteration amplifies rounding differences there, so the fp32-vs-fp64 gap is "
-                                         "reported overall and on the lanes that did converge; the parity bar is the "
-                                         "fp64 one below" % (args.dtype, float(np.median(cl1)))}
-        line["gpu_over_cpu"] = value / base["value"]
-        # the parity dtype: the same kernels in fp64 on the first lanes of the batch against the fp64 oracle
-        # (north_star's 1e-5 bar on the control sequence; tests/test_gpu_parity.py is the gate, this is the record)
-        n64 = int(min(n, 4096))
-        opt64 = pkg.BatchOptimization(params, max_batch=n64, dtype=torch.float64, device=local_rank)
-        opt64.set_pipeline(args.pipeline)
-        o64 = opt64.step(torch.tensor(x0_np[:, :n64], dtype=torch.float64, device=dev), DYN_UI, 0.0)
-        e64 = np.abs(o64.u.cpu().numpy() - u_cpu[:, :n64]).max(axis=0)
-        line["parity_f64"] = {"lanes": n64, "max_abs_du_max": float(e64.max()), "max_abs_du_median": float(np.median(e64)),
-                              "bar": 1e-5, "note": "GPU fp64 (same kernels, pipeline %s) vs fp64 oracle, same workload"
-                                                   % opt64.pipeline()}
-    if gather is not None:
-        # what rank 0 holds after the last step: the control sequences of all ranks, in global problem order
-        full = gather.assembled(state["slot"])
-        line["gathered"] = {"shape": list(full.shape), "own_block_intact": bool(torch.equal(full[:, :B], out.u))}
-    if dist.is_initialized():
-        dist.destroy_process_group()
+        if base is not None:
+            try:
+                ps, err = parity_stats(u_primary[:, :n].double().cpu().numpy(), u_cpu, st[:n], st_cpu)
+                cl1 = eq_primary[:n].double().cpu().numpy()
+                conv = cl1 < 1e-3   # lanes whose shooting defects have closed after the fixed 5 iterations
+                ps.update({"fraction_within_1e-2": float((err < 1e-2).mean()), "converged_lanes": int(conv.sum()),
+                           "max_abs_du_median_on_converged_lanes": float(np.median(err[conv])) if conv.any() else None,
+                           "note": "GPU %s vs fp64 oracle on the cpu_baseline sample; these cold-start swing-up problems "
+                                   "are far from converged after 5 iterations (median |c|_1 %.1f) and the SQP iteration "
+                                   "amplifies rounding differences there; the parity bar is the fp64 one (parity_f64)"
+                                   % (args.dtype, float(np.median(cl1)))})
+                line["parity_sample"] = ps
+            except Exception as exc:  # noqa: BLE001
+                line["parity_sample"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            if u64 is not None:
+                try:
+                    ps64, _ = parity_stats(u64[:, :n], u_cpu, st64[:n], st_cpu)
+                    ps64.update({"bar": 1e-5, "batch": B,
+                                 "note": "GPU fp64 (the fp64 record above, all of its lanes the CPU sample covers) vs the "
+                                         "fp64 oracle, same inputs"})
+                    line["parity_f64"] = ps64
+                except Exception as exc:  # noqa: BLE001
+                    line["parity_f64"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     # RCCL writes a version banner through C stdio, which is flushed at exit: flush it now so that the JSON line
     # is the last line on stdout
     import ctypes
     sys.stdout.flush()
     ctypes.CDLL(None).fflush(None)
     print(json.dumps(line), flush=True)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=262144, help="problems per GPU")
+    ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-fp64", action="store_true", help="skip the fp64 record")
+    ap.add_argument("--no-variants", action="store_true", help="skip the secondary measurements (SURVEY 8d)")
+    ap.add_argument("--pipeline", choices=["auto", "split", "fused"], default="auto")
+    return ap.parse_args(argv)
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process only starts the ranks and relays rank 0's line
+        rc, out0 = launch_ranks(args.gpus, sys.argv[1:])
+        ln = last_json_line(out0)
+        if ln is None or rc != 0:
+            sys.stderr.write(out0)
+            raise SystemExit(rc or 1)
+        print(ln, flush=True)
+        return
+    run_rank(args)
 
 
 if __name__ == "__main__":

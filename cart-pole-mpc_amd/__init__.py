@@ -21,3 +21,14 @@ def __getattr__(name):
         from . import batch
         return getattr(batch, name)
     raise AttributeError(name)
+
+
+def pypendulum():
+    """The `pypendulum` extension module (names of wrapper/wrapper.cc:40-98) built in lib/ by build.build_host()."""
+    import importlib
+    import os
+    import sys
+    lib_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
+    if lib_dir not in sys.path:
+        sys.path.insert(0, lib_dir)
+    return importlib.import_module("pypendulum")

@@ -203,6 +203,10 @@ class BatchOptimization:
     def has_previous_solution(self):
         return bool(capi.load().cpmpc_has_previous_solution(self._h))
 
+    def previous_solution_batch(self):
+        """Problems [0, n) hold a previous solution (warm start); the others cold-start at the next step."""
+        return int(capi.load().cpmpc_previous_solution_batch(self._h))
+
     def set_previous_solution(self, z):
         _require_cuda_tensor(z, "z", self.dtype)
         if z.dim() != 2 or z.shape[0] != self.dim:

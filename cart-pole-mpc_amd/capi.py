@@ -31,8 +31,8 @@ SYMBOLS = [
     "cpmpc_default_params", "cpmpc_default_solver_opts", "cpmpc_last_error", "cpmpc_device_count",
     "cpmpc_create", "cpmpc_destroy", "cpmpc_supported_state_spacing", "cpmpc_step_batch",
     "cpmpc_reset", "cpmpc_set_previous_solution", "cpmpc_get_solution",
-    "cpmpc_has_previous_solution", "cpmpc_dim", "cpmpc_num_states", "cpmpc_dtype",
-    "cpmpc_step_batch_host", "cpmpc_set_previous_solution_host", "cpmpc_get_solution_host",
+    "cpmpc_has_previous_solution", "cpmpc_previous_solution_batch", "cpmpc_dim", "cpmpc_num_states", "cpmpc_dtype",
+    "cpmpc_step_batch_host", "cpmpc_step_batch_host_ex", "cpmpc_set_previous_solution_host", "cpmpc_get_solution_host",
     "cpmpc_dynamics_batch", "cpmpc_rk4_batch", "cpmpc_linearize_batch", "cpmpc_sim_step_batch",
     "cpmpc_sim_step_batch_host", "cpmpc_model_state_dim", "cpmpc_model_num_params", "cpmpc_create_model",
     "cpmpc_model", "cpmpc_dynamics_batch_model", "cpmpc_rk4_batch_model", "cpmpc_sim_step_batch_model",
@@ -102,6 +102,20 @@ class StepOutputs(C.Structure):
         ("final_cost", C.c_void_p),
         ("final_eq_l1", C.c_void_p),
         ("guess", C.c_void_p),
+        ("solution", C.c_void_p),
+    ]
+
+
+class StepHostOutputs(C.Structure):
+    """cpmpc_step_host_outputs: HOST pointers, every one nullable."""
+    _fields_ = [
+        ("u", C.POINTER(C.c_double)),
+        ("predicted", C.POINTER(C.c_double)),
+        ("status", C.POINTER(C.c_int32)),
+        ("iterations", C.POINTER(C.c_int32)),
+        ("final_cost", C.POINTER(C.c_double)),
+        ("final_eq_l1", C.POINTER(C.c_double)),
+        ("solution", C.POINTER(C.c_double)),
     ]
 
 
@@ -150,10 +164,13 @@ def load():
     L.cpmpc_set_previous_solution.argtypes = [vp, i64, vp, vp]
     L.cpmpc_get_solution.argtypes = [vp, i64, vp, vp]
     L.cpmpc_has_previous_solution.argtypes = [vp]
+    L.cpmpc_previous_solution_batch.argtypes = [vp]
+    L.cpmpc_previous_solution_batch.restype = i64
     L.cpmpc_dim.argtypes = [vp]
     L.cpmpc_num_states.argtypes = [vp]
     L.cpmpc_dtype.argtypes = [vp]
     L.cpmpc_step_batch_host.argtypes = [vp, i64, _dp, _dp, dbl, _dp, _dp, _ip, _ip, _dp, _dp]
+    L.cpmpc_step_batch_host_ex.argtypes = [vp, i64, _dp, _dp, dbl, C.POINTER(StepHostOutputs)]
     L.cpmpc_set_previous_solution_host.argtypes = [vp, i64, _dp]
     L.cpmpc_get_solution_host.argtypes = [vp, i64, _dp]
     L.cpmpc_dynamics_batch.argtypes = [i32, i64, _dp, vp, vp, _dp, vp, vp, vp, vp]

@@ -179,10 +179,16 @@ struct cpmpc_solver {
   char *zx, *zu, *dzx, *dzu, *Phi, *Gam, *cs, *Wk, *Tk, *sc;
   int32_t* ist;
   void* sin_table = nullptr;
-  int has_prev = 0;
-  // staging for the *_host entry points (lazily allocated)
+  int64_t prev_B = 0;  // problems [0, prev_B) hold a previous solution; Reset() -> 0
+  // staging for the *_host entry points (lazily allocated, grown on demand, owned by the handle): a device buffer,
+  // its pinned host mirror and a stream, so that a host-pointer call is one async copy in, the kernels, one async
+  // copy out and a single synchronisation
   void* stage = nullptr;
+  void* pin = nullptr;
   size_t stage_bytes = 0;
+  hipStream_t hstream = nullptr;
+  hipEvent_t ev_last = nullptr;  // end of the last device-pointer call on a caller's stream; hstream waits on it
+  bool ev_pending = false;
   // profiling
   int profiling = 0;
   std::vector<ProfSpan> spans;
@@ -308,6 +314,11 @@ extern "C" int cpmpc_create_model(const cpmpc_params* params, const cpmpc_solver
     delete s;
     return fail(CPMPC_ERR_HIP, "hipMemcpy failed: %s", hipGetErrorString(e));
   }
+  // index list of the staged fused pipeline (4 bytes per problem + two counters): allocated here, never in a step
+  if (hipMalloc((void**)&s->active, ((size_t)s->cap + 2) * sizeof(int32_t)) != hipSuccess) {
+    (void)hipGetLastError();
+    s->active = nullptr;  // staging stays off for this handle (same results, single launch)
+  }
   *out = s;
   return CPMPC_OK;
 }
@@ -331,6 +342,9 @@ extern "C" void cpmpc_destroy(cpmpc_solver* s) {
   if (s->ws) (void)hipFree(s->ws);
   if (s->sin_table) (void)hipFree(s->sin_table);
   if (s->stage) (void)hipFree(s->stage);
+  if (s->pin) (void)hipHostFree(s->pin);
+  if (s->hstream) (void)hipStreamDestroy(s->hstream);
+  if (s->ev_last) (void)hipEventDestroy(s->ev_last);
   if (s->active) (void)hipFree(s->active);
   delete s;
 }
@@ -339,11 +353,12 @@ extern "C" int cpmpc_dim(const cpmpc_solver* s) { return s ? s->dim : -1; }
 extern "C" int cpmpc_num_states(const cpmpc_solver* s) { return s ? s->S : -1; }
 extern "C" int cpmpc_dtype(const cpmpc_solver* s) { return s ? s->dtype : -1; }
 extern "C" int cpmpc_model(const cpmpc_solver* s) { return s ? s->model : -1; }
-extern "C" int cpmpc_has_previous_solution(const cpmpc_solver* s) { return s ? s->has_prev : 0; }
+extern "C" int cpmpc_has_previous_solution(const cpmpc_solver* s) { return (s && s->prev_B > 0) ? 1 : 0; }
+extern "C" int64_t cpmpc_previous_solution_batch(const cpmpc_solver* s) { return s ? s->prev_B : 0; }
 
 extern "C" int cpmpc_reset(cpmpc_solver* s) {  // Optimization::Reset, optimization.hpp:83
   if (!s) return fail(CPMPC_ERR_INVALID_ARG, "null solver");
-  s->has_prev = 0;
+  s->prev_B = 0;
   return CPMPC_OK;
 }
 
@@ -410,6 +425,15 @@ extern "C" int cpmpc_profile_read(cpmpc_solver* s, int kernel, double* total_ms,
   return CPMPC_OK;
 }
 
+// Host-pointer entry points run on the handle's own stream.  Once one has been used, every device-pointer call on a
+// caller's stream leaves an event behind so that the next host-pointer call is ordered after it.
+static void track_caller_stream(cpmpc_solver* s, hipStream_t stream) {
+  if (s->ev_last != nullptr && stream != s->hstream) {
+    (void)hipEventRecord(s->ev_last, stream);
+    s->ev_pending = true;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------------
@@ -471,7 +495,7 @@ static void fill_args(const cpmpc_solver* s, int64_t B, SolverArgs<R, M>& a) {
   a.rel_tol = (R)p.relative_exit_tol;
   a.fo_tol = (R)p.absolute_first_derivative_tol;
   a.mu_init = (R)p.equality_penalty_initial;
-  a.has_prev = s->has_prev;
+  a.prev_B = s->prev_B;
   using V4 = typename VecT<R>::V4;
   using XVn = XV<R, M::NX>;
   a.zx = (XVn*)s->zx;
@@ -631,6 +655,7 @@ static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* 
     a.cost_out = (R*)out->final_cost;
     a.eq_out = (R*)out->final_eq_l1;
     a.guess_out = (R*)out->guess;
+    a.sol_out = (R*)out->solution;
   }
   const dim3 gridB = grid_for(B);
   ProfSpan sp;
@@ -651,11 +676,7 @@ static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* 
     // a batch that fits the machine in one round of resident waves (2 per SIMD) ends with its slowest wave either
     // way: staging would only add launches
     if (s->stage_auto && (B * (int64_t)(s->S - 1) + 63) / 64 <= 2048) staged = false;
-    if (staged && s->active == nullptr &&
-        hipMalloc((void**)&s->active, ((size_t)s->cap + 2) * sizeof(int32_t)) != hipSuccess) {
-      s->active = nullptr;
-      staged = false;  // out of memory for the index list: fall back to the single launch (same results)
-    }
+    if (s->active == nullptr) staged = false;  // no index list (allocation failed at creation): single launch, same results
     a.active_list = nullptr;
     a.active_count = nullptr;
     a.iter_cap = total;
@@ -670,7 +691,7 @@ static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* 
       a.prev_total = B;
       a.remaining = total - done;
       span_begin(s, CPMPC_KERNEL_FUSED, stream, &sp);
-      HIP_TRY(hipMemsetAsync(count, 0, sizeof(int32_t), stream));
+      const hipError_t memset_rc = hipMemsetAsync(count, 0, sizeof(int32_t), stream);
       hipLaunchKernelGGL(compact_active_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, stream,
                          (const int32_t*)(s->ist + (size_t)IS_STATUS * (size_t)s->cap),
                          (const int32_t*)(s->ist + (size_t)IS_ITERS * (size_t)s->cap), total, B, s->active, count);
@@ -678,7 +699,11 @@ static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* 
       a.active_count = count;
       const int k = (total - done < s->stage_next) ? (total - done) : s->stage_next;
       launch_fused<R, M>(a, s->S - 1, s->SP, k, stream);
-      span_end(s, stream, &sp);
+      span_end(s, stream, &sp);  // the span is closed (its events recycled) before any early return
+      if (memset_rc != hipSuccess) {
+        if (B > s->prev_B) s->prev_B = B;  // prepare has already shifted the warm start: keep the handle consistent
+        return fail(CPMPC_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(memset_rc));
+      }
     }
   } else {
     for (int it = 0; it < (int)s->params.max_iterations; ++it) {
@@ -696,7 +721,7 @@ static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* 
   span_end(s, stream, &sp);
 
   HIP_TRY(hipGetLastError());
-  s->has_prev = 1;  // previous_solution_ = solver_->variables()  (optimization.cc:85)
+  if (B > s->prev_B) s->prev_B = B;  // previous_solution_ = solver_->variables()  (optimization.cc:85), per problem
   return CPMPC_OK;
 }
 
@@ -713,6 +738,7 @@ extern "C" int cpmpc_step_batch(cpmpc_solver* s, int64_t B, const cpmpc_step_inp
   DeviceGuard guard(s->device);
   int rc = CPMPC_OK;
   CPMPC_DISPATCH(s->dtype, s->model, (rc = step_batch_impl<R, M>(s, B, in, out, (hipStream_t)stream)));
+  track_caller_stream(s, (hipStream_t)stream);
   return rc;
 }
 
@@ -728,7 +754,8 @@ extern "C" int cpmpc_set_previous_solution(cpmpc_solver* s, int64_t B, const voi
                  hipLaunchKernelGGL((pack_z_kernel<R, M::NX>), grid_for(B), dim3(64), 0, (hipStream_t)stream, B,
                                     s->cap, s->S, s->N, (const R*)z, (XV<R, M::NX>*)s->zx, (R*)s->zu));
   HIP_TRY(hipGetLastError());
-  s->has_prev = 1;
+  if (B > s->prev_B) s->prev_B = B;
+  track_caller_stream(s, (hipStream_t)stream);
   return CPMPC_OK;
 }
 
@@ -747,42 +774,62 @@ extern "C" int cpmpc_get_solution(cpmpc_solver* s, int64_t B, void* z_out, void*
 // host-pointer convenience (staging copies around the same GPU path)
 // ------------------------------------------------------------------------------------------------
 static int ensure_stage(cpmpc_solver* s, size_t bytes) {
+  if (s->hstream == nullptr) {
+    hipError_t e = hipStreamCreateWithFlags(&s->hstream, hipStreamNonBlocking);
+    if (e != hipSuccess) return fail(CPMPC_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+    e = hipEventCreateWithFlags(&s->ev_last, hipEventDisableTiming);
+    if (e != hipSuccess) return fail(CPMPC_ERR_HIP, "hipEventCreate failed: %s", hipGetErrorString(e));
+    // device-pointer calls made before this first host-pointer call were not tracked by ev_last: order after them once
+    HIP_TRY(hipDeviceSynchronize());
+  }
+  if (s->ev_pending) {  // a device-pointer call on a caller's stream came in between: run after it
+    HIP_TRY(hipStreamWaitEvent(s->hstream, s->ev_last, 0));
+    s->ev_pending = false;
+  }
   if (s->stage_bytes >= bytes) return CPMPC_OK;
   if (s->stage) (void)hipFree(s->stage);
+  if (s->pin) (void)hipHostFree(s->pin);
   s->stage = nullptr;
+  s->pin = nullptr;
   s->stage_bytes = 0;
-  hipError_t e = hipMalloc(&s->stage, bytes);
-  if (e != hipSuccess) return fail(CPMPC_ERR_ALLOC, "hipMalloc of %zu staging bytes failed: %s", bytes, hipGetErrorString(e));
-  s->stage_bytes = bytes;
+  const size_t want = bytes < 4096 ? 4096 : bytes;
+  hipError_t e = hipMalloc(&s->stage, want);
+  if (e != hipSuccess) return fail(CPMPC_ERR_ALLOC, "hipMalloc of %zu staging bytes failed: %s", want, hipGetErrorString(e));
+  e = hipHostMalloc(&s->pin, want, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    (void)hipFree(s->stage);
+    s->stage = nullptr;
+    return fail(CPMPC_ERR_ALLOC, "hipHostMalloc of %zu staging bytes failed: %s", want, hipGetErrorString(e));
+  }
+  s->stage_bytes = want;
   return CPMPC_OK;
-}
-
-template <typename R>
-static void to_dev_type(const double* src, size_t n, std::vector<R>& dst) {
-  dst.resize(n);
-  for (size_t i = 0; i < n; ++i) dst[i] = (R)src[i];
 }
 
 template <typename R, typename M>
 static int step_host_impl(cpmpc_solver* s, int64_t B, const double* x0_host, const double* dyn_shared_host,
-                          double set_point, double* u_host, double* predicted_host, int32_t* status_host,
-                          int32_t* iterations_host, double* final_cost_host, double* final_eq_l1_host) {
+                          double set_point, const cpmpc_step_host_outputs& ho) {
+  // staging layout, identical on the device and in the pinned mirror:
+  //   [x0 | u | cost | eq | status | iters | solution | predicted]      (the optional tails last: one copy back)
   const size_t nB = (size_t)B;
   const size_t n_x0 = (size_t)M::NX * nB, n_u = (size_t)s->N * nB, n_pred = (size_t)M::NX * (size_t)s->N * nB;
-  const size_t bytes = (n_x0 + n_u + n_pred + 2 * nB) * sizeof(R) + 2 * nB * sizeof(int32_t);
+  const size_t n_sol = (size_t)s->dim * nB;
+  const size_t bytes = (n_x0 + n_u + 2 * nB + n_sol + n_pred) * sizeof(R) + 2 * nB * sizeof(int32_t) + 64;
   int rc = ensure_stage(s, bytes);
   if (rc) return rc;
   R* d_x0 = (R*)s->stage;
   R* d_u = d_x0 + n_x0;
-  R* d_pred = d_u + n_u;
-  R* d_cost = d_pred + n_pred;
+  R* d_cost = d_u + n_u;
   R* d_eq = d_cost + nB;
   int32_t* d_status = (int32_t*)(d_eq + nB);
   int32_t* d_iters = d_status + nB;
+  // the real-typed tail starts 8-byte aligned after the 2 nB int32
+  R* d_sol = (R*)(((uintptr_t)(d_iters + nB) + 7) & ~(uintptr_t)7);
+  R* d_pred = d_sol + n_sol;
+  R* h_x0 = (R*)s->pin;
+  const hipStream_t st = s->hstream;
 
-  std::vector<R> h;
-  to_dev_type<R>(x0_host, n_x0, h);
-  HIP_TRY(hipMemcpy(d_x0, h.data(), n_x0 * sizeof(R), hipMemcpyHostToDevice));
+  for (size_t i = 0; i < n_x0; ++i) h_x0[i] = (R)x0_host[i];
+  HIP_TRY(hipMemcpyAsync(d_x0, h_x0, n_x0 * sizeof(R), hipMemcpyHostToDevice, st));
 
   cpmpc_step_inputs in;
   memset(&in, 0, sizeof in);
@@ -792,45 +839,59 @@ static int step_host_impl(cpmpc_solver* s, int64_t B, const double* x0_host, con
   cpmpc_step_outputs out;
   memset(&out, 0, sizeof out);
   out.u = d_u;
-  out.predicted = predicted_host ? d_pred : nullptr;
+  out.predicted = ho.predicted ? d_pred : nullptr;
   out.status = d_status;
   out.iterations = d_iters;
   out.final_cost = d_cost;
   out.final_eq_l1 = d_eq;
-  rc = step_batch_impl<R, M>(s, B, &in, &out, nullptr);
+  out.solution = ho.solution ? d_sol : nullptr;
+  rc = step_batch_impl<R, M>(s, B, &in, &out, st);
   if (rc) return rc;
-  HIP_TRY(hipStreamSynchronize(nullptr));
+  // one copy back, from u to the end of what was asked for
+  char* h_base = (char*)s->pin;
+  const char* d_base = (const char*)s->stage;
+  const char* d_end = ho.predicted ? (const char*)(d_pred + n_pred)
+                                   : (ho.solution ? (const char*)(d_sol + n_sol) : (const char*)(d_iters + nB));
+  const size_t off_u = (size_t)((const char*)d_u - d_base);
+  HIP_TRY(hipMemcpyAsync(h_base + off_u, d_u, (size_t)(d_end - (const char*)d_u), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
 
-  auto fetch = [&](const R* dsrc, double* hdst, size_t n) -> int {
-    if (!hdst) return CPMPC_OK;
-    h.resize(n);
-    HIP_TRY(hipMemcpy(h.data(), dsrc, n * sizeof(R), hipMemcpyDeviceToHost));
+  auto fetch = [&](const R* dsrc, double* hdst, size_t n) {
+    if (!hdst) return;
+    const R* h = (const R*)(h_base + ((const char*)dsrc - d_base));
     for (size_t i = 0; i < n; ++i) hdst[i] = (double)h[i];
-    return CPMPC_OK;
   };
-  if ((rc = fetch(d_u, u_host, n_u))) return rc;
-  if ((rc = fetch(d_pred, predicted_host, n_pred))) return rc;
-  if ((rc = fetch(d_cost, final_cost_host, nB))) return rc;
-  if ((rc = fetch(d_eq, final_eq_l1_host, nB))) return rc;
-  if (status_host) HIP_TRY(hipMemcpy(status_host, d_status, nB * sizeof(int32_t), hipMemcpyDeviceToHost));
-  if (iterations_host) HIP_TRY(hipMemcpy(iterations_host, d_iters, nB * sizeof(int32_t), hipMemcpyDeviceToHost));
+  fetch(d_u, ho.u, n_u);
+  fetch(d_cost, ho.final_cost, nB);
+  fetch(d_eq, ho.final_eq_l1, nB);
+  fetch(d_sol, ho.solution, n_sol);
+  fetch(d_pred, ho.predicted, n_pred);
+  const int32_t* h_status = (const int32_t*)(h_base + ((const char*)d_status - d_base));
+  if (ho.status) memcpy(ho.status, h_status, nB * sizeof(int32_t));
+  if (ho.iterations) memcpy(ho.iterations, h_status + nB, nB * sizeof(int32_t));
   return CPMPC_OK;
+}
+
+extern "C" int cpmpc_step_batch_host_ex(cpmpc_solver* s, int64_t B, const double* x0_host,
+                                        const double* dyn_shared_host, double set_point,
+                                        const cpmpc_step_host_outputs* out) {
+  if (!s || !x0_host || !dyn_shared_host || !out) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
+  if (B < 1) return fail(CPMPC_ERR_INVALID_ARG, "B must be >= 1");
+  if (B > s->cap) return fail(CPMPC_ERR_BATCH, "B exceeds capacity");
+  if (!std::isfinite(set_point)) return fail(CPMPC_ERR_INVALID_ARG, "set_point must be finite");
+  DeviceGuard guard(s->device);
+  int rc = CPMPC_OK;
+  CPMPC_DISPATCH(s->dtype, s->model, (rc = step_host_impl<R, M>(s, B, x0_host, dyn_shared_host, set_point, *out)));
+  return rc;
 }
 
 extern "C" int cpmpc_step_batch_host(cpmpc_solver* s, int64_t B, const double* x0_host,
                                      const double* dyn_shared_host, double set_point, double* u_host,
                                      double* predicted_host, int32_t* status_host, int32_t* iterations_host,
                                      double* final_cost_host, double* final_eq_l1_host) {
-  if (!s || !x0_host || !dyn_shared_host) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
-  if (B < 1) return fail(CPMPC_ERR_INVALID_ARG, "B must be >= 1");
-  if (B > s->cap) return fail(CPMPC_ERR_BATCH, "B exceeds capacity");
-  if (!std::isfinite(set_point)) return fail(CPMPC_ERR_INVALID_ARG, "set_point must be finite");
-  DeviceGuard guard(s->device);
-  int rc = CPMPC_OK;
-  CPMPC_DISPATCH(s->dtype, s->model,
-                 (rc = step_host_impl<R, M>(s, B, x0_host, dyn_shared_host, set_point, u_host, predicted_host,
-                                            status_host, iterations_host, final_cost_host, final_eq_l1_host)));
-  return rc;
+  const cpmpc_step_host_outputs out = {u_host, predicted_host, status_host, iterations_host, final_cost_host,
+                                       final_eq_l1_host, nullptr};
+  return cpmpc_step_batch_host_ex(s, B, x0_host, dyn_shared_host, set_point, &out);
 }
 
 extern "C" int cpmpc_set_previous_solution_host(cpmpc_solver* s, int64_t B, const double* z_host) {
@@ -841,15 +902,15 @@ extern "C" int cpmpc_set_previous_solution_host(cpmpc_solver* s, int64_t B, cons
   int rc = ensure_stage(s, n * s->esize);
   if (rc) return rc;
   if (s->dtype == CPMPC_F32) {
-    std::vector<float> h;
-    to_dev_type<float>(z_host, n, h);
-    HIP_TRY(hipMemcpy(s->stage, h.data(), n * 4, hipMemcpyHostToDevice));
+    float* h = (float*)s->pin;
+    for (size_t i = 0; i < n; ++i) h[i] = (float)z_host[i];
   } else {
-    HIP_TRY(hipMemcpy(s->stage, z_host, n * 8, hipMemcpyHostToDevice));
+    memcpy(s->pin, z_host, n * 8);
   }
-  rc = cpmpc_set_previous_solution(s, B, s->stage, nullptr);
+  HIP_TRY(hipMemcpyAsync(s->stage, s->pin, n * s->esize, hipMemcpyHostToDevice, s->hstream));
+  rc = cpmpc_set_previous_solution(s, B, s->stage, s->hstream);
   if (rc) return rc;
-  HIP_TRY(hipStreamSynchronize(nullptr));
+  HIP_TRY(hipStreamSynchronize(s->hstream));
   return CPMPC_OK;
 }
 
@@ -860,15 +921,15 @@ extern "C" int cpmpc_get_solution_host(cpmpc_solver* s, int64_t B, double* z_hos
   const size_t n = (size_t)s->dim * (size_t)B;
   int rc = ensure_stage(s, n * s->esize);
   if (rc) return rc;
-  rc = cpmpc_get_solution(s, B, s->stage, nullptr);
+  rc = cpmpc_get_solution(s, B, s->stage, s->hstream);
   if (rc) return rc;
-  HIP_TRY(hipStreamSynchronize(nullptr));
+  HIP_TRY(hipMemcpyAsync(s->pin, s->stage, n * s->esize, hipMemcpyDeviceToHost, s->hstream));
+  HIP_TRY(hipStreamSynchronize(s->hstream));
   if (s->dtype == CPMPC_F32) {
-    std::vector<float> h(n);
-    HIP_TRY(hipMemcpy(h.data(), s->stage, n * 4, hipMemcpyDeviceToHost));
+    const float* h = (const float*)s->pin;
     for (size_t i = 0; i < n; ++i) z_host[i] = (double)h[i];
   } else {
-    HIP_TRY(hipMemcpy(z_host, s->stage, n * 8, hipMemcpyDeviceToHost));
+    memcpy(z_host, s->pin, n * 8);
   }
   return CPMPC_OK;
 }
@@ -999,6 +1060,49 @@ extern "C" int cpmpc_sim_step_batch(int dtype, int64_t B, const double* dyn_shar
                                     stream);
 }
 
+// Staging of the handle-less host-pointer plant step: per host thread and device, grown on demand and kept (a
+// Simulator::Step per 10 ms tick must not allocate; simulator.cc:11-36 has no allocation either).
+struct SimStage {
+  int device = -1;
+  void* dev = nullptr;
+  void* pin = nullptr;
+  size_t bytes = 0;
+  hipStream_t stream = nullptr;
+  // never freed: at thread/process exit the HIP runtime may already be gone (a few KB per calling thread)
+};
+static thread_local SimStage g_sim_stage;
+
+static int ensure_sim_stage(size_t bytes) {
+  SimStage& g = g_sim_stage;
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (g.device != dev) {
+    if (g.dev) (void)hipFree(g.dev);
+    if (g.pin) (void)hipHostFree(g.pin);
+    if (g.stream) (void)hipStreamDestroy(g.stream);
+    g.dev = g.pin = nullptr;
+    g.stream = nullptr;
+    g.bytes = 0;
+    g.device = dev;
+  }
+  if (g.stream == nullptr) HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+  if (g.bytes >= bytes) return CPMPC_OK;
+  if (g.dev) (void)hipFree(g.dev);
+  if (g.pin) (void)hipHostFree(g.pin);
+  g.dev = g.pin = nullptr;
+  g.bytes = 0;
+  const size_t want = bytes < 4096 ? 4096 : bytes;
+  HIP_TRY(hipMalloc(&g.dev, want));
+  hipError_t e = hipHostMalloc(&g.pin, want, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    (void)hipFree(g.dev);
+    g.dev = nullptr;
+    return fail(CPMPC_ERR_ALLOC, "hipHostMalloc of %zu staging bytes failed: %s", want, hipGetErrorString(e));
+  }
+  g.bytes = want;
+  return CPMPC_OK;
+}
+
 extern "C" int cpmpc_sim_step_batch_host(int64_t B, const double* dyn_shared_host, double dt, const double* u_host,
                                          const double* fext_host, double* state_host) {
   if (!dyn_shared_host || !u_host || !state_host) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
@@ -1007,22 +1111,21 @@ extern "C" int cpmpc_sim_step_batch_host(int64_t B, const double* dyn_shared_hos
     if (!std::isfinite(u_host[i])) return fail(CPMPC_ERR_INVALID_ARG, "u = %g is not finite (simulator.cc:14)", u_host[i]);
   int rc = current_device_ok();
   if (rc) return rc;
-  double* d = nullptr;
-  HIP_TRY(hipMalloc((void**)&d, (size_t)5 * (size_t)B * sizeof(double)));
-  double* d_state = d;
-  double* d_u = d + 4 * B;
-  hipError_t e = hipMemcpy(d_state, state_host, (size_t)4 * B * sizeof(double), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(d_u, u_host, (size_t)B * sizeof(double), hipMemcpyHostToDevice);
-  if (e == hipSuccess) {
-    rc = cpmpc_sim_step_batch(CPMPC_F64, B, dyn_shared_host, dt, d_u, fext_host, nullptr, d_state, nullptr);
-    if (rc == CPMPC_OK) {
-      e = hipStreamSynchronize(nullptr);
-      if (e == hipSuccess) e = hipMemcpy(state_host, d_state, (size_t)4 * B * sizeof(double), hipMemcpyDeviceToHost);
-    }
-  }
-  (void)hipFree(d);
+  const size_t nB = (size_t)B;
+  rc = ensure_sim_stage(5 * nB * sizeof(double));
   if (rc) return rc;
-  if (e != hipSuccess) return fail(CPMPC_ERR_HIP, "HIP copy failed: %s", hipGetErrorString(e));
+  SimStage& g = g_sim_stage;
+  // [state 4B | u B]: one copy in, the kernel, one copy out, one synchronisation
+  double* h = (double*)g.pin;
+  double* d = (double*)g.dev;
+  memcpy(h, state_host, 4 * nB * sizeof(double));
+  memcpy(h + 4 * nB, u_host, nB * sizeof(double));
+  HIP_TRY(hipMemcpyAsync(d, h, 5 * nB * sizeof(double), hipMemcpyHostToDevice, g.stream));
+  rc = cpmpc_sim_step_batch(CPMPC_F64, B, dyn_shared_host, dt, d + 4 * nB, fext_host, nullptr, d, g.stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(h, d, 4 * nB * sizeof(double), hipMemcpyDeviceToHost, g.stream));
+  HIP_TRY(hipStreamSynchronize(g.stream));
+  memcpy(state_host, h, 4 * nB * sizeof(double));
   return CPMPC_OK;
 }
 

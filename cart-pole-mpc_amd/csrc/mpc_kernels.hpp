@@ -124,7 +124,7 @@ struct SolverArgs {
   R lam_init, lam_fail_init, lam_up, lam_down, lam_min, lam_max;
   R bx_lim, u_lim;
   R rel_tol, fo_tol, mu_init;
-  int has_prev;
+  int64_t prev_B;  // problems [0, prev_B) hold a previous solution (warm start); the others start cold
   // workspace (device)
   XVn* zx;   // [S]        shooting nodes of the iterate          } persist between calls:
   R* zu;     // [N]        controls of the iterate                } the warm start
@@ -161,6 +161,7 @@ struct SolverArgs {
   R* cost_out;
   R* eq_out;
   R* guess_out;
+  R* sol_out;  // [dim][B] packed solution (MapKey order)
 };
 
 // Terminal rows of problem p (optimization.cc:236-267): residual weight Rw[t] (1 for an equality row) and
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(256) void prepare_kernel(const SolverArgs<R, M> a) 
 
   // BuildProblem reads u_prev before the previous solution is overwritten (optimization.cc:288-291)
   R u_prev = R(0);
-  if (a.has_prev) {
+  if ((int64_t)p < a.prev_B) {  // per problem: a controller with no previous solution starts cold (optimization.cc:46-68)
     u_prev = a.zu[p];
     // shift the controls left by one, duplicate the last (optimization.cc:54-57)
     for (int kk = 0; kk + 1 < a.N; ++kk) a.zu[(int64_t)kk * st + p] = a.zu[(int64_t)(kk + 1) * st + p];
@@ -936,6 +937,15 @@ __global__ __launch_bounds__(256) void finalize_kernel(const SolverArgs<R, M> a)
   if (a.ls_out) a.ls_out[p] = a.ist[IS_LS_EVALS * st + p];
   if (a.cost_out) a.cost_out[p] = a.sc[SC_F_LAST * st + p];
   if (a.eq_out) a.eq_out[p] = a.sc[SC_CN_LAST * st + p];
+  if (a.sol_out) {  // previous_solution_ = solver_->variables() (optimization.cc:85), packed in MapKey order
+    for (int s = 0; s < a.S; ++s) {
+      R xv[NX];
+      unpack<R, NX>(a.zx[(int64_t)s * st + p], xv);
+#pragma unroll
+      for (int t = 0; t < NX; ++t) a.sol_out[(int64_t)(NX * s + t) * ob + p] = xv[t];
+    }
+    for (int i = 0; i < a.N; ++i) a.sol_out[(int64_t)(NX * a.S + i) * ob + p] = a.zu[(int64_t)i * st + p];
+  }
   if (a.pred_out) {
     const typename M::Consts k = load_consts(a, p);
     const ExtForce<R> fe{R(0), R(0), R(0)};

@@ -91,8 +91,10 @@ OptimizationOutputs Optimization::Step(const SingleCartPoleState& current_state,
   std::vector<double> u(N), pred(4 * N);
   std::int32_t status = 0, iterations = 0;
   double cost = 0.0, eq = 0.0;
-  int rc = cpmpc_step_batch_host(solver_, 1, x0.data(), dyn.data(), b_x_set_point, u.data(), pred.data(),
-                                 &status, &iterations, &cost, &eq);
+  // one round trip: the solution z (previous_solution_ of the next Step, optimization.cc:84-85) comes back with u
+  std::vector<double> z(static_cast<std::size_t>(cpmpc_dim(solver_)));
+  const cpmpc_step_host_outputs ho = {u.data(), pred.data(), &status, &iterations, &cost, &eq, z.data()};
+  const int rc = cpmpc_step_batch_host_ex(solver_, 1, x0.data(), dyn.data(), b_x_set_point, &ho);
   if (rc != CPMPC_OK) Throw(rc);
 
   OptimizationOutputs out;
@@ -107,9 +109,7 @@ OptimizationOutputs Optimization::Step(const SingleCartPoleState& current_state,
   for (std::size_t k = 0; k < N; ++k)  // [N][4][1]
     out.predicted_states.emplace_back(pred[4 * k + 0], pred[4 * k + 1], pred[4 * k + 2], pred[4 * k + 3]);
 
-  previous_solution_.resize(static_cast<std::size_t>(cpmpc_dim(solver_)));
-  rc = cpmpc_get_solution_host(solver_, 1, previous_solution_.data());  // optimization.cc:85
-  if (rc != CPMPC_OK) Throw(rc);
+  previous_solution_ = std::move(z);  // optimization.cc:85
   return out;
 }
 

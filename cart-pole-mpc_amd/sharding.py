@@ -23,9 +23,14 @@ class ResultGather:
     """Gathers equally sized [N, B_local] result blocks to `dst`, double-buffered so that the
     gather of step i overlaps the solve of step i+1 (the collective runs on RCCL's stream)."""
 
-    def __init__(self, n_rows, b_local, dtype, device, dst=0, depth=2, force=False):
-        """force=True runs the collective even in a world of one (exercises the backend on a single GPU)."""
+    def __init__(self, n_rows, b_local, dtype, device, dst=0, depth=2, force=False, via_host=False):
+        """force=True runs the collective even in a world of one (exercises the backend on a single GPU).
+        via_host=True copies each block to the host first (a gloo process group next to GPU results: the
+        rehearsal of several ranks on one device, which RCCL refuses)."""
         self.dst = dst
+        self.via_host = via_host
+        if via_host:
+            device = "cpu"
         self.depth = depth
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
@@ -51,6 +56,8 @@ class ResultGather:
         slot = self.slot()
         self.wait_slot(slot)
         if self.active:
+            if self.via_host:
+                block = block.cpu()
             self.pending[slot] = dist.gather(block, self.recv[slot] if self.rank == self.dst else None,
                                              dst=self.dst, async_op=True)
         self.i += 1

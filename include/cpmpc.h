@@ -145,6 +145,8 @@ typedef struct cpmpc_step_outputs {
   void* final_cost;    /* [B]        1/2 |r|^2 at the returned solution's last evaluation */
   void* final_eq_l1;   /* [B]        |c|_1 there */
   void* guess;         /* [dim][B]   the initial guess handed to the solver */
+  void* solution;      /* [dim][B]   the solution z = solver_->variables() (optimization.cc:85), MapKey order: what the
+                        *            next Step reports as OptimizationOutputs::previous_solution (optimization.cc:84) */
 } cpmpc_step_outputs;
 
 /* Replaces Optimization::Step (optimization.cc:39-97) for B problems in lock-step.  Warm start
@@ -162,6 +164,11 @@ int cpmpc_set_previous_solution(cpmpc_solver* s, int64_t B, const void* z, void*
  * of the NEXT step, optimization.cc:84); z_out is [dim][B]. */
 int cpmpc_get_solution(cpmpc_solver* s, int64_t B, void* z_out, void* stream);
 int cpmpc_has_previous_solution(const cpmpc_solver* s);
+/* Warm-start state is per problem, as one Optimization object per controller is in the reference
+ * (optimization.cc:46-68: a controller without a previous solution starts from the sinusoid guess): problems
+ * [0, n) hold a previous solution, n = the largest B stepped or set since the last cpmpc_reset; a later step with a
+ * larger B warm-starts those and cold-starts the rest. */
+int64_t cpmpc_previous_solution_batch(const cpmpc_solver* s);
 
 int cpmpc_dim(const cpmpc_solver* s);        /* 4*S + N (optimization.cc:204-205) */
 int cpmpc_num_states(const cpmpc_solver* s); /* OptimizationParams::NumStates (optimization.hpp:52) */
@@ -174,6 +181,20 @@ int cpmpc_step_batch_host(cpmpc_solver* s, int64_t B, const double* x0_host,
                           const double* dyn_shared_host, double set_point, double* u_host,
                           double* predicted_host, int32_t* status_host, int32_t* iterations_host,
                           double* final_cost_host, double* final_eq_l1_host);
+/* The same with the outputs in a struct of HOST pointers (every one nullable), including the solution z, so that
+ * Optimization::Step (which also keeps previous_solution_, optimization.cc:85) is ONE round trip: one copy in, the
+ * kernels, one copy out, one synchronisation, on the handle's own stream and pinned staging. */
+typedef struct cpmpc_step_host_outputs {
+  double* u;             /* [N][B] */
+  double* predicted;     /* [N][4][B] */
+  int32_t* status;       /* [B] */
+  int32_t* iterations;   /* [B] */
+  double* final_cost;    /* [B] */
+  double* final_eq_l1;   /* [B] */
+  double* solution;      /* [dim][B] */
+} cpmpc_step_host_outputs;
+int cpmpc_step_batch_host_ex(cpmpc_solver* s, int64_t B, const double* x0_host, const double* dyn_shared_host,
+                             double set_point, const cpmpc_step_host_outputs* out);
 int cpmpc_set_previous_solution_host(cpmpc_solver* s, int64_t B, const double* z_host);
 int cpmpc_get_solution_host(cpmpc_solver* s, int64_t B, double* z_host);
 

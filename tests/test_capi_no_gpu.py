@@ -41,6 +41,7 @@ def test_header_is_plain_c_and_struct_layouts_match(lib, pkg, tmp_path):
         "cpmpc_solver_opts": [f for f, _ in pkg.capi.SolverOpts._fields_],
         "cpmpc_step_inputs": [f for f, _ in pkg.capi.StepInputs._fields_],
         "cpmpc_step_outputs": [f for f, _ in pkg.capi.StepOutputs._fields_],
+        "cpmpc_step_host_outputs": [f for f, _ in pkg.capi.StepHostOutputs._fields_],
     }
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "cpmpc.h"', "int main(void) {"]
     for st, fs in fields.items():
@@ -54,7 +55,8 @@ def test_header_is_plain_c_and_struct_layouts_match(lib, pkg, tmp_path):
                            "-o", str(exe), str(src)])
     got = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
     mirrors = {"cpmpc_params": pkg.capi.Params, "cpmpc_solver_opts": pkg.capi.SolverOpts,
-               "cpmpc_step_inputs": pkg.capi.StepInputs, "cpmpc_step_outputs": pkg.capi.StepOutputs}
+               "cpmpc_step_inputs": pkg.capi.StepInputs, "cpmpc_step_outputs": pkg.capi.StepOutputs,
+               "cpmpc_step_host_outputs": pkg.capi.StepHostOutputs}
     for st, cls in mirrors.items():
         assert int(got[st]) == C.sizeof(cls), st
         for f, _ in cls._fields_:

@@ -5,7 +5,8 @@ Writes
   profiles/<tag>_kernel_stats.csv    the --kernel-trace --stats table (our kernels only)
   profiles/<tag>_pmc_summary.json    per-kernel, per-launch averages of every PMC counter collected
                                      (separate --pmc passes), plus HBM traffic per launch
-  profiles/traffic_latest.json       {kernel: HBM bytes per launch} read by bench.py ("traffic")
+  profiles/traffic_latest.json       {kernel: HBM bytes per launch} read by bench.py ("traffic"); fp64 runs write
+                                     traffic_latest_f64.json
 
 HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE
 come from separate passes, are in KiB, and FETCH_SIZE under-reports by a pattern-dependent factor on
@@ -109,7 +110,8 @@ def main():
             }
     with open(os.path.join(out_dir, tag + "_pmc_summary.json"), "w") as fh:
         json.dump(summary, fh, indent=1, sort_keys=True)
-    with open(os.path.join(out_dir, "traffic_latest.json"), "w") as fh:
+    tname = "traffic_latest.json" if dtype == "f32" else "traffic_latest_%s.json" % dtype
+    with open(os.path.join(out_dir, tname), "w") as fh:
         json.dump({"tag": tag, "dtype": dtype, "batch": batch, "per_launch_bytes": traffic,
                    "source": "profiles/%s_pmc_summary.json" % tag}, fh, indent=1, sort_keys=True)
     print(json.dumps(summary, indent=1, sort_keys=True))
