@@ -80,6 +80,12 @@ struct Math<float> {
   static __device__ __forceinline__ float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
   static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 #endif
+  static __device__ __forceinline__ float div(float a, float b) { return a / b; }
+  // |v| and 1/|v| (0 when |v| = 0: the hardware sqrt flushes a denormal argument to zero, see cartpole_accel)
+  static __device__ __forceinline__ void sqrt_inv(float x, float& s, float& r) {
+    s = sqrt(x);
+    r = (0.0f < s) ? rcp(s) : 0.0f;
+  }
   static __device__ __forceinline__ float fabs(float x) { return ::fabsf(x); }
   static __device__ __forceinline__ float trunc(float x) { return ::truncf(x); }
   static __device__ __forceinline__ float fma(float a, float b, float c) { return ::fmaf(a, b, c); }
@@ -156,12 +162,60 @@ struct Math<double> {
     p = ::fma(r * r, p, r);
     const double two_n = ::ldexp(1.0, (int)nf);              // n in [-116, 0]
     const double t = ::fma(two_n, p, two_n - 1.0);           // expm1(y) in (-1, 0]
-    return ::copysign(-t / (t + 2.0), x);
+    return ::copysign(div(-t, t + 2.0), x);
   }
 #endif
   static __device__ __forceinline__ double tanh_scaled(double x, double scale, double) { return tanh(x * scale); }
+#if CPMPC_F64_LIBM
   static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
   static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
+  static __device__ __forceinline__ double div(double a, double b) { return a / b; }
+  static __device__ __forceinline__ void sqrt_inv(double x, double& s, double& r) {
+    s = ::sqrt(x);
+    r = (0.0 < s) ? 1.0 / s : 0.0;
+  }
+#else
+  // The compiler's IEEE division is 11 instructions around v_rcp_f64 (two v_div_scale, four refinement fma, the
+  // quotient and its residual, v_div_fmas, v_div_fixup) and its sqrt 15 around v_rsq_f64 (range scaling either side);
+  // an RK4 stage holds three reciprocals and a square root.  The operands here are ordinary magnitudes (no scaling
+  // needed), so: hardware seed + two Newton steps (each squares the error: seed >= 2^-23 -> 2^-46 -> below an ulp),
+  // and for a quotient one residual correction.  Results are within an ulp of the correctly rounded ones
+  // (test_fp64_math_routines_over_wide_ranges); x = 0 gives NaN instead of inf (no caller divides by zero on a
+  // problem that is still being solved: pivots and |v| are tested first).
+  static __device__ __forceinline__ double rcp(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    double e = ::fma(-x, y, 1.0);
+    y = ::fma(y, e, y);
+    e = ::fma(-x, y, 1.0);
+    return ::fma(y, e, y);
+  }
+  static __device__ __forceinline__ double div(double a, double b) {
+    const double y = rcp(b);
+    const double q = a * y;
+    return ::fma(::fma(-b, q, a), y, q);
+  }
+  // sqrt(x) and 1/sqrt(x) together (coupled Goldschmidt iteration from v_rsq_f64): the drag terms need both.
+  // x = 0 -> (0, 0): "no drag at rest" (single_pendulum_dynamics.hpp:75-84 guards on 0 < |v|^2).
+  static __device__ __forceinline__ void sqrt_inv(double x, double& s, double& r) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double e = ::fma(-h, g, 0.5);
+    g = ::fma(g, e, g);
+    h = ::fma(h, e, h);
+    e = ::fma(-h, g, 0.5);
+    g = ::fma(g, e, g);
+    h = ::fma(h, e, h);
+    g = ::fma(::fma(-g, g, x), h, g);
+    const bool zero = (x == 0.0);
+    s = zero ? 0.0 : g;
+    r = zero ? 0.0 : h + h;
+  }
+  static __device__ __forceinline__ double sqrt(double x) {
+    double s, r;
+    sqrt_inv(x, s, r);
+    return s;
+  }
+#endif
   static __device__ __forceinline__ double fabs(double x) { return ::fabs(x); }
   static __device__ __forceinline__ double trunc(double x) { return ::trunc(x); }
   static __device__ __forceinline__ double fma(double a, double b, double c) { return ::fma(a, b, c); }
@@ -268,7 +322,8 @@ __device__ __forceinline__ void cartpole_accel(const CartPoleConsts<R>& k, const
   const R vx = v - Lw * s;
   const R vy = Lw * c;
   const R n2 = vx * vx + vy * vy;
-  const R n = Math<R>::sqrt(n2);
+  R n, inv_n;  // |v| and 1/|v| (0 at rest); inv_n is only used by the partials
+  Math<R>::sqrt_inv(n2, n, inv_n);
   const R e = Lw - s * v;  // = c*vy - s*vx
   // the generated code guards these with |v|^2 > 0; at |v| = 0 the products are 0 anyway
   const R Dx = k.half_cd * n * vx;
@@ -291,8 +346,9 @@ __device__ __forceinline__ void cartpole_accel(const CartPoleConsts<R>& k, const
 
   if (WITH_J) {
     // partials of the drag terms with respect to (th, v, w); all vanish at |v| = 0 (the guard of the
-    // generated code), which a zero 1/|v| reproduces without a branch
-    const R inv_n = (R(0) < n2) ? Math<R>::rcp(n) : R(0);
+    // generated code), which a zero 1/|v| reproduces without a branch.  (The guard is on |v| itself, not |v|^2:
+    // the fp32 hardware sqrt flushes a denormal |v|^2 to |v| = 0, and 1/0 would turn the vanishing products
+    // below into NaN; in fp64 the two tests are equivalent.)
     // d|v|/d(th, v, w), with  vx + L w s = v  and  c vy - s vx = e  folded in
     const R dn0 = -(vy * v) * inv_n;
     const R dn1 = vx * inv_n;

@@ -141,9 +141,11 @@ def test_dynamics_branch_points(pkg, orc, dtype):
         assert (Jx[3, 0] == 0.0) == (Jo[3, 0] == 0.0), (tag, Jx[3, 0], Jo[3, 0])
         xn, A, Bm = pkg.rk4_batch(P, T(xr.reshape(4, 1), dtype), T([ur], dtype), 0.01, fext=fext)
         xo, Ao, Bo = orc.rk4(P, xr.astype(float), float(ur), 0.01, fb, fm)
-        assert np.abs(N_(xn)[:, 0] - xo).max() < (1e-13 if dtype == torch.float64 else 2e-6), tag
-        assert np.abs(N_(A)[:, :, 0] - Ao).max() < (1e-13 if dtype == torch.float64 else 2e-5), tag
-        assert np.abs(N_(Bm)[:, 0] - Bo).max() < (1e-13 if dtype == torch.float64 else 2e-6), tag
+        # (with v_mu at its 1e-6 floor the friction slope makes entries of A ~ 1e4: tolerances scale with the term size)
+        sa = max(1.0, np.abs(Ao).max())
+        assert np.abs(N_(xn)[:, 0] - xo).max() < (1e-13 if dtype == torch.float64 else 2e-6) * max(1.0, np.abs(xo).max()), tag
+        assert np.abs(N_(A)[:, :, 0] - Ao).max() < (1e-13 if dtype == torch.float64 else 2e-5) * sa, tag
+        assert np.abs(N_(Bm)[:, 0] - Bo).max() < (1e-13 if dtype == torch.float64 else 2e-6) * sa, tag
     print("branch points %s: worst f %.2e, worst J %.2e (relative to term size)" % (dtype, worst_f, worst_j))
 
 
