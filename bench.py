@@ -368,6 +368,26 @@ def parity_stats(u_gpu, u_cpu, st_gpu, st_cpu):
             "status_agree": int((st_gpu == st_cpu).sum())}, err
 
 
+def arbiter(u_gpu, u_cpu, x0_np, over, worst=256):
+    """Where GPU fp64 and the double oracle are furthest apart, which one moved?  The `worst` lanes by |u_gpu - u_oracle|
+    re-solved by the SAME restatement in x87 extended precision (oracle/cpmpc_oracle_ld.c, 64-bit significand): the
+    distance of each implementation from that answer is its own rounding sensitivity on the problem."""
+    from oracle import oracle as orc
+    err = np.abs(u_gpu - u_cpu).max(axis=0)
+    idx = np.argsort(err)[-worst:]
+    u_ld, _, _, _, eq = orc.step_batch_cold_ld(orc.default_opt_params(**over), DYN_UI, 0.0, x0_np[:, idx])
+    e_gpu = np.abs(u_gpu[:, idx] - u_ld).max(axis=0)
+    e_cpu = np.abs(u_cpu[:, idx] - u_ld).max(axis=0)
+    return {"lanes": int(idx.size), "gpu_vs_oracle_max": float(err[idx].max()),
+            "gpu_vs_extended_max": float(e_gpu.max()), "oracle_vs_extended_max": float(e_cpu.max()),
+            "gpu_vs_extended_median": float(np.median(e_gpu)), "oracle_vs_extended_median": float(np.median(e_cpu)),
+            "lanes_gpu_over_1e-5_vs_extended": int((e_gpu > 1e-5).sum()),
+            "lanes_oracle_over_1e-5_vs_extended": int((e_cpu > 1e-5).sum()),
+            "median_final_eq_l1_of_these_lanes": float(np.median(eq)),
+            "note": "the %d lanes with the largest |u_gpu - u_oracle| re-solved in extended precision (same algorithm, "
+                    "same constants)" % idx.size}
+
+
 def run_rank(args):
     import torch
     import torch.distributed as dist
@@ -542,6 +562,7 @@ def run_rank(args):
                                  "note": "GPU fp64 (the fp64 record above, all of its lanes the CPU sample covers) vs the "
                                          "fp64 oracle, same inputs"})
                     line["parity_f64"] = ps64
+                    line["parity_f64"]["arbiter"] = arbiter(u64[:, :n], u_cpu, x0_np[:, :n], over)
                 except Exception as exc:  # noqa: BLE001
                     line["parity_f64"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     # RCCL writes a version banner through C stdio, which is flushed at exit: flush it now so that the JSON line

@@ -758,20 +758,51 @@ __global__ CPMPC_QPLS_BOUNDS void qp_ls_kernel(const SolverArgs<R, M> a) {
         Lm[i][j] = v * inv;
       }
     }
-    R y[NX];
+    auto ldl_solve = [&](const R (&b)[NX], R (&x)[NX]) {
+      R y[NX];
 #pragma unroll
-    for (int i = 0; i < NX; ++i) {
-      R v = hv[i] - rho[i];
+      for (int i = 0; i < NX; ++i) {
+        R v = b[i];
 #pragma unroll
-      for (int m = 0; m < i; ++m) v -= Lm[i][m] * y[m];
-      y[i] = v;
-    }
+        for (int m = 0; m < i; ++m) v -= Lm[i][m] * y[m];
+        y[i] = v;
+      }
 #pragma unroll
-    for (int i = NX - 1; i >= 0; --i) {
-      R v = y[i] / dv[i];
+      for (int i = NX - 1; i >= 0; --i) {
+        R v = y[i] / dv[i];
 #pragma unroll
-      for (int m = i + 1; m < NX; ++m) v -= Lm[m][i] * q[m];
-      q[i] = v;
+        for (int m = i + 1; m < NX; ++m) v -= Lm[m][i] * x[m];
+        x[i] = v;
+      }
+    };
+    R rhs[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) rhs[i] = hv[i] - rho[i];
+    ldl_solve(rhs, q);
+    // One step of iterative refinement of q with the residual taken through the factored operator
+    // (S = W^T D^-1 W is a normal-equations matrix; see mpc_fused_body.inc).  fp64 only: in fp32 the rest of the
+    // pipeline rounds far above what this recovers, and the extra pass over W is HBM traffic here.
+    if constexpr (sizeof(R) == 8) {
+      R acc[NX];
+#pragma unroll
+      for (int r = 0; r < NX; ++r) acc[r] = R(0);
+      for (int kk = 0; kk < N; ++kk) {
+        R wk[NX];
+        unpack<R, NX>(a.Wk[(int64_t)kk * st + p], wk);
+        const V4 tk = a.Tk[(int64_t)kk * st + p];
+        R om = wk[0] * q[0];
+#pragma unroll
+        for (int r = 1; r < NX; ++r) om += wk[r] * q[r];
+        const R t = om * tk.z;  // (w_k . q) / d_k
+#pragma unroll
+        for (int r = 0; r < NX; ++r) acc[r] += wk[r] * t;
+      }
+      R rq[NX], dq[NX];
+#pragma unroll
+      for (int r = 0; r < NX; ++r) rq[r] = rhs[r] - Dg[r] * q[r] - acc[r];
+      ldl_solve(rq, dq);
+#pragma unroll
+      for (int r = 0; r < NX; ++r) q[r] += dq[r];
     }
   }
   if (status == kTermNone && !pd_ok) status = kTermQpIndefinite;

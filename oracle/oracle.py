@@ -11,6 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libcpmpc_oracle.so")
+_LIB_LD_PATH = os.path.join(_HERE, "libcpmpc_oracle_ld.so")
 
 
 def build(force=False):
@@ -23,6 +24,17 @@ def build(force=False):
     subprocess.check_call(["make", "-C", _HERE, "-B", "libcpmpc_oracle.so"],
                           stdout=subprocess.DEVNULL)
     return _LIB_PATH
+
+
+def build_ld(force=False):
+    """Compile the extended-precision build of the same restatement (cpmpc_oracle_ld.c: long double arithmetic)."""
+    srcs = [os.path.join(_HERE, f) for f in ("cpmpc_oracle_ld.c", "cpmpc_oracle.c", "cpmpc_oracle.h")]
+    if (not force and os.path.exists(_LIB_LD_PATH)
+            and os.path.getmtime(_LIB_LD_PATH) >= max(os.path.getmtime(f) for f in srcs)):
+        return _LIB_LD_PATH
+    subprocess.check_call(["make", "-C", _HERE, "-B", "libcpmpc_oracle_ld.so"], stdout=subprocess.DEVNULL,
+                          stderr=subprocess.DEVNULL)
+    return _LIB_LD_PATH
 
 
 class OptParams(C.Structure):
@@ -167,6 +179,22 @@ def lib():
     L.orc_step_batch_cold_model.restype = C.c_int
     _lib = L
     return L
+
+
+_lib_ld = None
+
+
+def lib_ld():
+    global _lib_ld
+    if _lib_ld is None:
+        build_ld()
+        L = C.CDLL(_LIB_LD_PATH)
+        ip = C.POINTER(C.c_int32)
+        L.orcld_step_batch_cold_d.argtypes = [C.c_int, C.POINTER(OptParams), C.POINTER(SolverOpts), _dp, C.c_double,
+                                              C.c_int64, _dp, _dp, ip, ip, ip, _dp, C.c_int]
+        L.orcld_step_batch_cold_d.restype = C.c_int
+        _lib_ld = L
+    return _lib_ld
 
 
 def default_opt_params(**overrides):
@@ -447,3 +475,23 @@ def step_batch_cold(p, dyn, set_point, x0_soa, opts=None, want_pred=False, num_t
         _ptr(x0), _ptr(u), _ptr(pred), status.ctypes.data_as(C.POINTER(C.c_int32)),
         iters.ctypes.data_as(C.POINTER(C.c_int32)), int(num_threads))
     return u, pred, status, iters, used
+
+
+def step_batch_cold_ld(p, dyn, set_point, x0_soa, opts=None, num_threads=0, model="single"):
+    """The same cold-start re-plan in EXTENDED precision (x87 long double, oracle/cpmpc_oracle_ld.c): the arbiter for
+    lanes on which the GPU and the double oracle end up apart.  Returns (u [N,B] rounded to double, status, iters,
+    line-search evaluations, final |c|_1)."""
+    m = MODELS[model]
+    nx = model_nx(m)
+    x0 = np.ascontiguousarray(x0_soa, dtype=np.float64)
+    assert x0.ndim == 2 and x0.shape[0] == nx
+    B, N = x0.shape[1], int(p.window_length)
+    dyn = _vec(dyn, model_np(m))
+    u = np.zeros((N, B))
+    status, iters, evals = (np.zeros(B, dtype=np.int32) for _ in range(3))
+    eq = np.zeros(B)
+    ip = C.POINTER(C.c_int32)
+    lib_ld().orcld_step_batch_cold_d(m, C.byref(p), C.byref(opts) if opts is not None else None, _ptr(dyn),
+                                     float(set_point), B, _ptr(x0), _ptr(u), status.ctypes.data_as(ip),
+                                     iters.ctypes.data_as(ip), evals.ctypes.data_as(ip), _ptr(eq), int(num_threads))
+    return u, status, iters, evals, eq

@@ -1,6 +1,7 @@
 """Where the fused SQP kernel spends its time: builds the library with -DCPMPC_FUSED_TIMING (shader-clock
 counters per phase, see CPMPC_TICK in csrc/mpc_fused.hpp) into tools/_build/ and runs the benchmark workload
-once.  Run from the repo root on a GPU box:  python tools/phase_timing.py"""
+once.  Run from the repo root on a GPU box:  python tools/phase_timing.py [f32|f64]   (`--build-only` compiles the
+timing library here, where there is no GPU, so that it travels to the box)"""
 import os, subprocess, sys, ctypes, importlib, numpy as np, torch
 sys.path.insert(0, '.')
 _LIB = os.path.abspath("tools/_build/lib_timing/libcpmpc.so")
@@ -10,6 +11,9 @@ if not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(
     os.makedirs(os.path.dirname(_LIB), exist_ok=True)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize",
                            "-shared", "-fPIC", "-DCPMPC_FUSED_TIMING", "-Iinclude", "-o", _LIB, _SRC])
+if "--build-only" in sys.argv:
+    sys.exit(0)
+DT = torch.float64 if "f64" in sys.argv else torch.float32
 os.environ["CPMPC_LIB"] = _LIB
 pkg = importlib.import_module("cart-pole-mpc_amd")
 lib = ctypes.CDLL(os.environ["CPMPC_LIB"])
@@ -17,8 +21,8 @@ DYN_UI = [1.0, 0.1, 0.25, 9.81, 0.05, 0.1, 0.02, 0.8, 100.0]
 rng = np.random.default_rng(1000)
 B = 262144
 x0 = np.stack([rng.uniform(-0.6, 0.6, B), rng.uniform(-np.pi, np.pi, B), rng.uniform(-1, 1, B), rng.uniform(-3, 3, B)])
-x0t = torch.tensor(x0, dtype=torch.float32, device='cuda')
-opt = pkg.BatchOptimization(pkg.default_params(max_iterations=5, relative_exit_tol=0.0, absolute_first_derivative_tol=0.0), max_batch=B, dtype=torch.float32, device=0)
+x0t = torch.tensor(x0, dtype=DT, device='cuda')
+opt = pkg.BatchOptimization(pkg.default_params(max_iterations=5, relative_exit_tol=0.0, absolute_first_derivative_tol=0.0), max_batch=B, dtype=DT, device=0)
 opt.set_pipeline("fused")
 names = ["linearize", "d-chain", "sweep1 local pass", "boundary chain + combine", "group sums + rows + LDLT + sweep1b", "sweep2", "penalty + line search", "accept + prologue + epilogue"]
 buf = (ctypes.c_ulonglong * 8)()
@@ -28,6 +32,7 @@ for rep in range(3):
     torch.cuda.synchronize()
     lib.cpmpc_debug_phase_cycles(buf)
 tot = sum(buf)
+print("dtype", DT)
 for n, v in zip(names, buf):
     print("%-32s %14d  %5.1f%%" % (n, v, 100.0 * v / tot))
 waves = B * 4 // 64
