@@ -97,7 +97,7 @@ struct Math<float> {
 // about one ulp on the ranges this path produces (-DCPMPC_F64_LIBM=1 restores the library calls for A/B):
 //   sincos  Cody-Waite reduction by pi/2 in three 33-bit pieces (exact products for |x| < 2^20 * pi/2; pole angles
 //           are wrapped to (-pi, pi] at every node) + the classic degree-13 / degree-14 minimax kernels on
-//           [-pi/4, pi/4]; non-finite or astronomically large arguments give NaN, as a diverged lane should
+//           [-pi/4, pi/4]; beyond that range a finite argument gives (0, 1) and a non-finite one NaN
 //   tanh    -t / (t + 2) with t = expm1(-2|x|): n = rint(y / ln 2), r = y - n ln 2 (hi/lo), degree-13 Taylor
 //           kernel on |r| <= ln2/2, t = 2^n p + (2^n - 1); exact odd symmetry, full relative accuracy at small |x|
 #ifndef CPMPC_F64_LIBM
@@ -131,14 +131,18 @@ struct Math<double> {
     const double hz = 0.5 * z;
     const double w = 1.0 - hz;
     const double cr = w + (((1.0 - w) - hz) + z * z * cp);
-    // quadrant; |x| beyond the exact-reduction range (or non-finite) is not a state this path can hold
+    // quadrant.  |x| beyond the exact-reduction range is not an angle a live problem holds, but a diverging line
+    // search trial can: there the C library (and so the reference) still returns SOME value in [-1, 1], the merit of
+    // the trial stays finite-and-huge and the backtracking takes its "far too long" branch; a NaN here would take the
+    // other branch (measured on a double-pendulum problem: step halved instead of cut to a tenth, a different
+    // accepted step after five trials).  So: huge finite x -> (0, 1); inf / NaN -> NaN, as sin and cos do.
     const bool ok = ::fabs(kf) < 1048576.0;
     const int q = ok ? (int)kf : 0;
     const double ss = (q & 1) ? cr : sr;
     const double cc = (q & 1) ? sr : cr;
-    const double nan = __builtin_nan("");
-    s = ok ? ((q & 2) ? -ss : ss) : nan;
-    c = ok ? (((q + 1) & 2) ? -cc : cc) : nan;
+    const double zero_or_nan = x - x;  // 0 for a finite x, NaN otherwise
+    s = ok ? ((q & 2) ? -ss : ss) : zero_or_nan;
+    c = ok ? (((q + 1) & 2) ? -cc : cc) : 1.0 + zero_or_nan;
   }
   static __device__ __forceinline__ double tanh(double x) {
     double y = -2.0 * ::fabs(x);

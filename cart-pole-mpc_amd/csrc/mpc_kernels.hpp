@@ -900,6 +900,8 @@ __global__ CPMPC_QPLS_BOUNDS void qp_ls_kernel(const SolverArgs<R, M> a) {
       } else {
         const R denom = R(2) * (phi_t - phi0 - D * alpha);
         R a_new = (denom > R(0)) ? (-D * alpha * alpha / denom) : (a.shrink_max * alpha);
+        // a diverged trial (merit NaN / inf) is an overlong step like a finite astronomically large one: lower safeguard
+        if (!Math<R>::finite(phi_t)) a_new = a.shrink_min * alpha;
         if (!(a_new >= a.shrink_min * alpha)) a_new = a.shrink_min * alpha;
         if (a_new > a.shrink_max * alpha) a_new = a.shrink_max * alpha;
         alpha = a_new;

@@ -623,6 +623,12 @@ void orc_problem_eval(const orc_opt_params* p, const double dyn[9], const double
   problem_eval(&kModels[0], p, dyn, x_current, set_point, u_prev, z, r_cost, c_eq, J_cost, A_eq);
 }
 
+void orc_problem_eval_model(int model, const orc_opt_params* p, const double* dyn, const double* x_current,
+                            double set_point, double u_prev, const double* z, double* r_cost, double* c_eq,
+                            double* J_cost, double* A_eq) {
+  problem_eval(model_of(model), p, dyn, x_current, set_point, u_prev, z, r_cost, c_eq, J_cost, A_eq);
+}
+
 static double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 /* optimization/optimization.cc:309-329 */
@@ -643,6 +649,11 @@ static void retract(const orc_model* m, const orc_opt_params* p, const orc_solve
 void orc_retract(const orc_opt_params* p, const orc_solver_opts* o, const double* z, const double* dz,
                  double alpha, double* z_out) {
   retract(&kModels[0], p, o, z, dz, alpha, z_out);
+}
+
+void orc_retract_model(int model, const orc_opt_params* p, const orc_solver_opts* o, const double* z,
+                       const double* dz, double alpha, double* z_out) {
+  retract(model_of(model), p, o, z, dz, alpha, z_out);
 }
 
 /* ------------------------------------------------------------------------------------------- */
@@ -851,8 +862,13 @@ static int solve(const orc_model* m, const orc_opt_params* p, const orc_solver_o
         break;
       }
       {
+        /* a trial whose merit is not finite (the rollout diverged: inf - inf, or an overflow) is a step that is far
+         * too long, exactly like one whose merit is finite and astronomically large: cut to the lower safeguard.
+         * (Which of NaN / inf / 1e90 a diverged rollout produces is an accident of the arithmetic; the step
+         * length must not depend on it.) */
         const double denom = 2.0 * (phi_t - phi0 - D * alpha);
-        double a_new = (denom > 0.0) ? (-D * alpha * alpha / denom) : (o->ls_shrink_max * alpha);
+        double a_new = !isfinite(phi_t) ? (o->ls_shrink_min * alpha)
+                                        : ((denom > 0.0) ? (-D * alpha * alpha / denom) : (o->ls_shrink_max * alpha));
         if (!(a_new >= o->ls_shrink_min * alpha)) a_new = o->ls_shrink_min * alpha;
         if (a_new > o->ls_shrink_max * alpha) a_new = o->ls_shrink_max * alpha;
         alpha = a_new;

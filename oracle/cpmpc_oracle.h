@@ -142,6 +142,12 @@ void orc_problem_eval(const orc_opt_params* p, const double dyn[9], const double
 /* The retraction of optimization.cc:309-329: z <- clamp/mod(z + alpha dz). */
 void orc_retract(const orc_opt_params* p, const orc_solver_opts* o, const double* z,
                  const double* dz, double alpha, double* z_out);
+/* the same two for either model (ORC_MODEL_*) */
+void orc_problem_eval_model(int model, const orc_opt_params* p, const double* dyn, const double* x_current,
+                            double set_point, double u_prev, const double* z, double* r_cost, double* c_eq,
+                            double* J_cost, double* A_eq);
+void orc_retract_model(int model, const orc_opt_params* p, const orc_solver_opts* o, const double* z,
+                       const double* dz, double alpha, double* z_out);
 
 /* One equality-constrained Gauss-Newton QP on the full space, dense KKT + LU.
  * Returns 0 on success, nonzero if the KKT matrix is singular. */

@@ -38,6 +38,8 @@
 #define orc_opt_set_previous_solution orcld_opt_set_previous_solution
 #define orc_opt_step orcld_opt_step
 #define orc_problem_eval orcld_problem_eval
+#define orc_problem_eval_model orcld_problem_eval_model
+#define orc_retract_model orcld_retract_model
 #define orc_problem_shape orcld_problem_shape
 #define orc_problem_shape_model orcld_problem_shape_model
 #define orc_qp_solve orcld_qp_solve

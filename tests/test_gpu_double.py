@@ -104,17 +104,20 @@ def _step_vs_oracle(pkg, orc, over, x0, set_point, pipeline="auto"):
 @pytest.mark.parametrize("pipeline", ["split", "fused"])
 def test_double_step_parity_fixed_iterations(pkg, orc, pipeline):
     """5 SQP iterations, exits disabled, states up to 0.15 rad from upright (most of these do not converge
-    within the 0.4 s horizon): within 1e-5 of the oracle on u (fp64).  A lane whose line search runs to its last
-    trial with a penalty of ~1e5 interpolates its step from a difference of merit values of ~1e6 -- catastrophic
-    cancellation that turns ulp-level differences in sin/cos into a different step (measured: 1 lane of 320,
-    identical in both GPU pipelines); such lanes are bounded in number, the rest must agree."""
+    within the 0.4 s horizon): every lane within 1e-5 of the oracle on u (fp64).
+    Until round 2 one lane of the 320 ended 8.0 away, identically in both GPU pipelines, and was tolerated as
+    "cancellation".  The extended-precision build of the oracle (oracle/cpmpc_oracle_ld.c) showed the oracle was
+    right to 4e-10 and the GPU was not: on that problem the full step and the half step diverge, the oracle's
+    rollout ended finite-and-astronomic (|c|_1 = 5e91: step cut to a tenth) while the kernels' ended NaN (step
+    halved), so the five trials ran through different step lengths.  The rule now says what it always meant -- a
+    trial whose merit is not finite is an overlong step, lower safeguard -- in the oracle and in both pipelines."""
     rng = np.random.default_rng(5)
     x0 = near_upright(rng, 320)
     over = dict(OVER, max_iterations=5, relative_exit_tol=0.0, absolute_first_derivative_tol=0.0)
     out, ok, err, perr = _step_vs_oracle(pkg, orc, over, x0, 0.05, pipeline)
     assert ok.all()
-    assert (err < 1e-5).mean() >= 0.99 and np.median(err) < 1e-7
-    assert (perr < 1e-5).mean() >= 0.99
+    assert err.max() < 1e-5 and np.median(err) < 1e-7, np.sort(err)[-5:]
+    assert perr.max() < 1e-5
 
 
 SOFT = dict(state_spacing=5, th_final_cost_weight=200.0, th_dot_final_cost_weight=20.0, b_x_dot_final_cost_weight=20.0)
@@ -132,9 +135,9 @@ def test_double_step_parity_with_exits(pkg, orc, over, min_conv, pipeline):
     x0[0] *= 0.2
     x0[3:] *= 0.2
     out, ok, err, perr = _step_vs_oracle(pkg, orc, dict(OVER, **over), x0, 0.02, pipeline)
-    assert ok.mean() > 0.98
+    assert ok.all()
     assert (N_(out.final_eq_l1) < 1e-4).mean() >= min_conv
-    assert err[ok].max() < 1e-5 and perr[ok].max() < 1e-5
+    assert err.max() < 1e-5 and perr.max() < 1e-5
     assert len(set(N_(out.status).tolist())) >= 2
 
 
@@ -191,6 +194,6 @@ def test_config5_full_size(pkg, orc):
     u_cpu, _, st_cpu, _, _ = orc.step_batch_cold(orc.default_opt_params(**over), DYN, 0.0, x0[:, samp], model="double")
     err = np.abs(N_(out.u)[:, samp] - u_cpu).max(axis=0)
     assert (N_(out.status)[samp] == st_cpu).all()
-    assert (err < 1e-5).mean() > 0.97, np.sort(err)[-5:]
+    assert err.max() < 1e-5, np.sort(err)[-5:]
     e32 = np.abs(N_(u1.double())[:, samp] - u_cpu).max(axis=0)
     print("config 5: fp64 |du| max %.2e median %.2e;  fp32 median %.2e" % (err.max(), np.median(err), np.median(e32)))

@@ -76,9 +76,12 @@ def test_fp64_math_routines_over_wide_ranges(pkg, orc):
     xm[2] = -xm[2]
     fb, _, _ = pkg.dynamics_batch([1.0, 0.1, 0.25, 0.0, 0.05, 0.1, 0.0, 0.8, 100.0], T(xm), T(np.zeros(B)))
     assert torch.equal(fa[2], -fb[2])
-    bad = np.array([[0.0, np.inf, 0.0, 0.0], [0.0, 1e300, 0.0, 0.0], [0.0, np.nan, 0.0, 0.0]]).T
-    fn, _, _ = pkg.dynamics_batch(DYN_UI, T(bad), T(np.zeros(3)))
-    assert not torch.isfinite(fn[2:]).any()          # a state no lane can hold: non-finite out, never garbage
+    # angles no live problem holds: inf / NaN give NaN (as sin and cos do); a huge finite angle -- a diverging line
+    # search trial -- gives a finite, bounded result like the C library's, so that such a trial is rejected the same way
+    bad = np.array([[0.0, np.inf, 0.0, 0.0], [0.0, np.nan, 0.0, 0.0], [0.0, 1e300, 0.0, 0.0], [0.0, -3e9, 0.5, 1.0]]).T
+    fn, _, _ = pkg.dynamics_batch(DYN_UI, T(bad), T(np.zeros(4)))
+    assert not torch.isfinite(fn[2:, :2]).any()
+    assert torch.isfinite(fn[:, 2:]).all() and fn[2:, 2:].abs().max().item() < 1e3
 
 
 def test_survey_known_answers(pkg, survey_answers):
@@ -233,9 +236,8 @@ def test_step_parity_default_exits(pkg, orc):
     out, err, perr, st_ok, it_ok = _compare_step(pkg, orc, {}, x0)
     st = N_(out.status)
     assert len(set(st.tolist())) >= 2, "expected a mix of termination states"
-    assert st_ok.mean() > 0.995 and it_ok.mean() > 0.995
-    good = st_ok & it_ok
-    assert err[good].max() < 1e-5
+    assert st_ok.all() and it_ok.all()
+    assert err.max() < 1e-5
 
 
 @pytest.mark.parametrize("over", [
@@ -262,16 +264,12 @@ def test_step_parity_configurations(pkg, orc, over):
     x0 = random_states(rng, 192)
     x0[1, ::2] = np.pi / 2 + rng.uniform(-0.5, 0.5, 96)
     out, err, perr, st_ok, it_ok = _compare_step(pkg, orc, over, x0, dyn=DYN_TEST, set_point=0.1)
-    good = st_ok & it_ok
-    assert good.mean() > 0.98
-    # Lanes that converge must agree to 1e-5.  A lane that is still far from feasible after the last
-    # iteration is an expansive fixed-point iteration (rounding differences grow ~30x per SQP iteration,
-    # measured), so over long runs a small fraction of such lanes may drift apart: bound that fraction.
-    converged = good & (N_(out.final_eq_l1) < 1e-4)
-    if converged.any():
-        assert err[converged].max() < 1e-5, np.sort(err[converged])[-5:]
-        assert perr[converged].max() < 1e-5
-    assert (err[good] < 1e-5).mean() >= 0.99, np.sort(err[good])[-5:]
+    # every lane: same termination state, same iteration count, controls and predicted states within 1e-5 (before
+    # the multipliers of the terminal rows were refined -- DESIGN.md section 5 -- 1-2 % of the lanes of the longer
+    # runs drifted past 1e-5; since then none does)
+    assert st_ok.all() and it_ok.all()
+    assert err.max() < 1e-5, np.sort(err)[-5:]
+    assert perr.max() < 1e-5
 
 
 @pytest.mark.parametrize("pipeline", ["fused", "split"])
@@ -332,10 +330,9 @@ def test_step_parity_fuzz(pkg, orc, seed):
     x0 = random_states(rng, B)
     x0[1, ::2] = np.pi / 2 + rng.uniform(-0.4, 0.4, B // 2)
     out, err, perr, st_ok, it_ok = _compare_step(pkg, orc, over, x0, dyn=dyn, set_point=sp)
-    good = st_ok & it_ok
-    assert good.mean() >= 0.95, (over, dyn)
-    assert (err[good] < 1e-5).mean() >= 0.97, (over, dyn, np.sort(err[good])[-5:])
-    assert np.median(err[good]) < 1e-8
+    assert st_ok.all() and it_ok.all(), (over, dyn)           # every lane of every case
+    assert err.max() < 1e-5, (over, dyn, np.sort(err)[-5:])
+    assert np.median(err) < 1e-8
 
 
 def test_edge_batches(pkg, orc):
@@ -403,7 +400,7 @@ def test_per_problem_terminal_weights(pkg, orc, pipeline):
         uc, _, sc, _, _ = orc.step_batch_cold(orc.default_opt_params(**over), DYN_UI, 0.05, x0[:, b:b + 1])
         if sc[0] != st[b] or np.abs(u[:, b] - uc[:, 0]).max() >= 1e-5:
             bad += 1
-    assert bad <= B // 50, bad
+    assert bad == 0, bad   # every problem, each with its own mix of cost / equality rows
     # the handle's own weights given per problem: bitwise the shared path
     p = pkg.default_params(**NO_TOL)
     shared = np.array([[getattr(p, n)] * B for n in names])
@@ -571,18 +568,22 @@ def test_closed_loop_balances(pkg, dtype, tol):
                             pkg.capi.TERM["NON_FINITE"]]).any()
 
 
-def test_full_size_fp64_sample_parity(pkg, orc):
-    """fp64 at B = 65536: lanes sampled across the batch agree with the oracle to 1e-5."""
+def test_full_size_fp64_every_lane(pkg, orc):
+    """BASELINE configs[2]'s batch (262 144 problems, N = 40, 5 iterations, cold start) in the parity dtype: EVERY lane
+    within 1e-5 of the oracle, same termination state and iteration count (measured: worst lane 8e-7, 99th percentile
+    3e-10).  The oracle runs the whole batch on the host's cores (a few seconds on the GPU box's 16)."""
     rng = np.random.default_rng(21)
-    B = 65536
+    B = 262144
     x0 = random_states(rng, B)
     opt = pkg.BatchOptimization(pkg.default_params(**NO_TOL), max_batch=B, dtype=torch.float64, device=0)
     out = opt.step(T(x0), DYN_UI, 0.0)
-    samp = np.concatenate([np.arange(0, 64), np.arange(B - 64, B), rng.integers(0, B, 384)])
-    u_cpu, _, st_cpu, _, _ = orc.step_batch_cold(orc.default_opt_params(**NO_TOL), DYN_UI, 0.0, x0[:, samp])
-    err = np.abs(N_(out.u)[:, samp] - u_cpu).max(axis=0)
-    assert (N_(out.status)[samp] == st_cpu).all()
-    assert err.max() < 1e-5
+    import os
+    threads = min(len(os.sched_getaffinity(0)), 16)
+    u_cpu, _, st_cpu, it_cpu, _ = orc.step_batch_cold(orc.default_opt_params(**NO_TOL), DYN_UI, 0.0, x0, num_threads=threads)
+    err = np.abs(N_(out.u) - u_cpu).max(axis=0)
+    print("full batch fp64: |du| max %.2e p99 %.2e median %.2e" % (err.max(), np.quantile(err, 0.99), np.median(err)))
+    assert (N_(out.status) == st_cpu).all() and (N_(out.iterations) == it_cpu).all()
+    assert err.max() < 1e-5, np.sort(err)[-5:]
 
 
 def test_profiling_counts_launches(pkg):
@@ -620,8 +621,8 @@ def test_profiling_counts_launches(pkg):
 def test_long_horizons_fused(pkg, orc, over):
     """Horizons of 80 and 160 steps: 8 and 16 lanes per problem in the fused kernel (generic group traffic).
     Eliminating the states through 16 intervals of an unstable plant (1.6 s) is worse conditioned than the
-    oracle's full-space KKT solve: measured, both pipelines keep 99 % of the lanes within 1e-5 of the oracle at
-    N = 160 (worst lane 2e-4) and all of them at N = 80 (worst 5e-9)."""
+    oracle's full-space KKT solve; with the terminal multipliers refined through the factored operator every lane
+    of both pipelines stays within 1e-5 of the oracle at N = 80 and N = 160 (before: 99 % at N = 160, worst 2e-4)."""
     rng = np.random.default_rng(11)
     x0 = random_states(rng, 96)
     x0[1, ::2] = np.pi / 2 + rng.uniform(-0.3, 0.3, 48)
@@ -630,15 +631,15 @@ def test_long_horizons_fused(pkg, orc, over):
     out = opt.step(T(x0), DYN_UI, 0.0)
     u_cpu, _, st_cpu, it_cpu, _ = orc.step_batch_cold(orc.default_opt_params(**over), DYN_UI, 0.0, x0)
     ok = (N_(out.status) == st_cpu) & (N_(out.iterations) == it_cpu)
-    assert ok.mean() > 0.97
+    assert ok.all()
     err = np.abs(N_(out.u) - u_cpu).max(axis=0)
-    assert (err[ok] < 1e-5).mean() >= 0.97, np.sort(err[ok])[-5:]
+    assert err.max() < 1e-5, np.sort(err)[-5:]
     opt.set_pipeline("split")
     opt.reset()
     out2 = opt.step(T(x0), DYN_UI, 0.0)
     same = N_(out2.status) == N_(out.status)
     tol = 1e-6 if over["window_length"] <= 80 else 1e-4
-    assert (np.abs(N_(out2.u) - N_(out.u)).max(axis=0)[same] < tol).mean() > 0.97
+    assert same.all() and np.abs(N_(out2.u) - N_(out.u)).max() < tol
 
 
 def test_long_horizon_fp32_stays_finite(pkg):
@@ -674,16 +675,14 @@ def test_fused_with_groups_that_straddle_dpp_rows(pkg, orc, over):
     out = opt.step(T(x0), DYN_UI, 0.0, want_stats=True)
     u_cpu, _, st_cpu, it_cpu, _ = orc.step_batch_cold(orc.default_opt_params(**over), DYN_UI, 0.0, x0)
     ok = (N_(out.status) == st_cpu) & (N_(out.iterations) == it_cpu)
-    assert ok.mean() > 0.97
+    assert ok.all()
     err = np.abs(N_(out.u) - u_cpu).max(axis=0)
-    assert (err[ok] < 1e-5).mean() >= 0.98 and np.median(err[ok]) < 1e-8
+    assert err.max() < 1e-5 and np.median(err) < 1e-8
     opt.set_pipeline("split")
     opt.reset()
     out2 = opt.step(T(x0), DYN_UI, 0.0, want_stats=True)
-    same = N_(out2.status) == N_(out.status)
-    assert same.mean() > 0.97
-    assert (np.abs(N_(out2.u) - N_(out.u)).max(axis=0)[same] < 1e-6).mean() > 0.97
-    assert torch.equal(out2.ls_evals[T(same, torch.bool)], out.ls_evals[T(same, torch.bool)])
+    assert torch.equal(out2.status, out.status) and torch.equal(out2.ls_evals, out.ls_evals)
+    assert np.abs(N_(out2.u) - N_(out.u)).max() < 1e-6
 
 
 @pytest.mark.parametrize("over", [dict(NO_TOL), dict(), dict(state_spacing=5, max_iterations=6),
@@ -708,16 +707,15 @@ def test_fused_and_split_pipelines_agree(pkg, orc, over, dtype):
     a, b = outs["split"], outs["fused"]
     same = (a[1] == b[1]) & (a[2] == b[2]) & (a[3] == b[3])
     if dtype == torch.float64:
-        assert same.float().mean().item() > 0.995
-        d1 = (a[0] - b[0]).abs().max(dim=0).values[same]
+        assert same.all()
+        d1 = (a[0] - b[0]).abs().max(dim=0).values
         assert d1.max().item() < 1e-6
-        same2 = same & (a[5] == b[5])
-        assert ((a[4] - b[4]).abs().max(dim=0).values[same2] < 1e-5).float().mean().item() > 0.99
-        assert (a[6] - b[6]).abs().max(dim=0).values[same2].median().item() < 1e-9
+        same2 = a[5] == b[5]
+        assert same2.all() and (a[4] - b[4]).abs().max().item() < 1e-5
+        assert (a[6] - b[6]).abs().max(dim=0).values.median().item() < 1e-9
         # and both agree with the oracle
         u_cpu, _, st_cpu, _, _ = orc.step_batch_cold(orc.default_opt_params(**over), DYN_UI, 0.1, x0)
-        ok = N_(b[1]) == st_cpu
-        assert ok.mean() > 0.995 and np.abs(N_(b[0]) - u_cpu).max(axis=0)[ok].max() < 1e-5
+        assert (N_(b[1]) == st_cpu).all() and np.abs(N_(b[0]) - u_cpu).max() < 1e-5
     else:
         # fp32: the group-sum tree of the fused pipeline rounds differently from the split pipeline's serial
         # sums, which flips near-tie Armijo / exit decisions on a minority of lanes

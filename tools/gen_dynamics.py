@@ -14,12 +14,21 @@ solver next to the generated code:   a = M^-1 F,   da/dx_c = M^-1 (dF/dx_c - (dM
 da/du = M^-1 dF/du, which is cheaper and better conditioned than emitting the closed-form inverse the
 reference's generator emits (symbolic/sympy_utils.py:43-50).
 
-Model generated today: the double pendulum of symbolic/dynamics_double.py:25-107
-(state [b_x, th_1, th_2, b_x', th_1', th_2'], params (m_b, m_1, m_2, l_1, l_2, g), no dissipation).
+Models generated:
+  double  the double pendulum of symbolic/dynamics_double.py:25-107 (state [b_x, th_1, th_2, b_x', th_1', th_2'],
+          params (m_b, m_1, m_2, l_1, l_2, g), no dissipation): M, F, dF/dx, dM/dth as above.
+  single  the model that is on the hot path, symbolic/dynamics_single.py:58-143: smoothed Coulomb friction
+          (tanh(v / max(v_mu_b, 1e-6))), cubic air-drag power with the |v|^2 > 0 guard, bumper springs max(0, .),
+          external forces on base and mass.  Emitted in the reference generator's own form -- accelerations through
+          the closed-form 2x2 inverse, Jacobians by symbolic differentiation (symbolic/sympy_utils.py:43-50) -- with
+          the non-smooth pieces carried as opaque symbols plus their derivative rules, so the output is straight-line
+          code with per-lane selects, and with every parameter-only sub-expression split off into a constants
+          function evaluated once on the host.  -DCPMPC_GENERATED_SINGLE=1 builds the kernels on it instead of the
+          hand-written cartpole_accel (cartpole_device.hpp); tests/test_generated_dynamics.py holds the two together.
 
 Usage (from the repository root):  python tools/gen_dynamics.py
-Writes   oracle/double_pendulum_gen.inc            (C, double)
-         cart-pole-mpc_amd/csrc/double_pendulum_gen.hpp   (HIP device code, templated on the scalar)
+Writes   oracle/double_pendulum_gen.inc, oracle/single_pendulum_gen.inc          (C, double)
+         cart-pole-mpc_amd/csrc/double_pendulum_gen.hpp, single_pendulum_gen.hpp  (HIP device code, scalar-templated)
 """
 import os
 
@@ -98,7 +107,8 @@ class _Printer(C99CodePrinter):
         return super()._print_Pow(e)
 
     def _print_Float(self, e):
-        return "%s(%s)" % (self.scalar, C99CodePrinter._print_Float(self, e))
+        lit = C99CodePrinter._print_Float(self, e)
+        return lit if self.scalar == "double" else "%s(%s)" % (self.scalar, lit)
 
     def _print_Integer(self, e):
         return "%s(%d)" % (self.scalar, int(e)) if self.scalar != "double" else "%d.0" % int(e)
@@ -142,6 +152,220 @@ def emit(model, scalar, header):
     return "\n".join(lines) + "\n"
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# cart + single pole with dissipation, springs and external forces (symbolic/dynamics_single.py:58-143)
+# ------------------------------------------------------------------------------------------------------------------
+def derive_single():
+    """Accelerations a = (b_x'', th_1'') and their partials wrt x = (b_x, th_1, b_x', th_1') and u, as expressions in
+    the state, the control, the external forces, the parameters and these helper symbols (evaluated by the emitted
+    prologue, differentiated by the rules below):
+        s, c     sin th_1, cos th_1
+        tv       tanh(b_x' * ivm),  ivm = 1 / max(v_mu_b, 1e-6)          d tv / d b_x' = (1 - tv^2) ivm
+        n, inv_n |p_1'| and its reciprocal (0 at rest: the |v|^2 > 0 guard)  d n / d x_c = (p_1' . d p_1'/d x_c) inv_n
+        sr, sl   max(0, b_x - x_s), max(0, -x_s - b_x);  on_r, on_l their 0/1 slopes"""
+    bx, th, v, w, u = sp.symbols("b_x th_1 b_x_dot th_1_dot u", real=True)
+    m_b, m_1, l_1, g, mu_b, v_mu_b, c_d_1, x_s, k_s = prm = sp.symbols("m_b m_1 l_1 g mu_b v_mu_b c_d_1 x_s k_s", real=True)
+    fbx, fmx, fmy = sp.symbols("f_b_x f_m1_x f_m1_y", real=True)   # f_b_y does no work (b moves along x only)
+    s, c, tv, n, inv_n, sr, sl, on_r, on_l, ivm = sp.symbols("s c tv n inv_n sr sl on_r on_l ivm", real=True)
+    a0, a1 = sp.symbols("a0 a1", real=True)
+
+    # kinematics with sin / cos as symbols: d s = c d th, d c = -s d th
+    def d_th(e):
+        return sp.diff(e, th) + sp.diff(e, s) * c - sp.diff(e, c) * s
+
+    def ddt(e):  # total time derivative along (q, q', q'')
+        return sp.diff(e, bx) * v + d_th(e) * w + sp.diff(e, v) * a0 + sp.diff(e, w) * a1
+
+    b = sp.Matrix([bx, 0])
+    p1 = b + sp.Matrix([c, s]) * l_1                                   # dynamics_single.py:58-64
+    bd, p1d = b.applyfunc(ddt), p1.applyfunc(ddt)
+    T = (m_b * bd.dot(bd) + m_1 * p1d.dot(p1d)) / 2                     # :66-83
+    V = g * m_1 * p1[1]
+    L = T - V
+    Q_b = fbx * 1 + fmx * sp.diff(p1[0], bx) + fmy * sp.diff(p1[1], bx)   # :92-98
+    Q_th = fmx * d_th(p1[0]) + fmy * d_th(p1[1])
+    F_fric = -mu_b * (m_1 + m_b) * g * tv                                # :100-103
+    # drag power (1/6) c_d |p_1'|^3 enters through d/dq' : (1/2) c_d |p_1'|^2 d|p_1'|/dq' = (1/2) c_d n (p_1' . dp_1'/dq')
+    drag_v = sp.Rational(1, 2) * c_d_1 * n * (p1d[0] * sp.diff(p1d[0], v) + p1d[1] * sp.diff(p1d[1], v))     # :105-111
+    drag_w = sp.Rational(1, 2) * c_d_1 * n * (p1d[0] * sp.diff(p1d[0], w) + p1d[1] * sp.diff(p1d[1], w))
+    F_s = -k_s * sr + k_s * sl                                           # :113-115
+    el_b = ddt(sp.diff(L, v)) - sp.diff(L, bx) - u - Q_b - F_fric - F_s + drag_v      # :117-131
+    el_th = ddt(sp.diff(L, w)) - d_th(L) - Q_th + drag_w
+    el = [sp.expand(el_b), sp.expand(el_th)]
+    # A(x, x') x'' = f(x, x', u)  (sympy_utils.get_euler_lagrange_coefficients), closed-form 2x2 inverse (get_mat_inverse)
+    A = sp.Matrix(2, 2, lambda i, j: sp.diff(el[i], (a0, a1)[j]))
+    f = sp.Matrix([-(e.subs({a0: 0, a1: 0})) for e in el])
+    A = A.applyfunc(lambda e: sp.simplify(e.subs(c**2, 1 - s**2)))
+    det = sp.simplify((A[0, 0] * A[1, 1] - A[0, 1] * A[1, 0]).subs(c**2, 1 - s**2))
+    acc = sp.Matrix([(A[1, 1] * f[0] - A[0, 1] * f[1]) / det, (-A[1, 0] * f[0] + A[0, 0] * f[1]) / det])
+
+    # total derivatives through the helper symbols
+    vx, vy = p1d[0].subs({a0: 0, a1: 0}), p1d[1].subs({a0: 0, a1: 0})
+
+    def dn(var):   # d|p_1'| / d var,  var in (th, v, w)
+        dvx = d_th(vx) if var is th else sp.diff(vx, var)
+        dvy = d_th(vy) if var is th else sp.diff(vy, var)
+        return (vx * dvx + vy * dvy) * inv_n
+
+    def total(e, var):
+        if var is bx:
+            return sp.diff(e, bx) + sp.diff(e, sr) * on_r - sp.diff(e, sl) * on_l
+        if var is th:
+            return d_th(e) + sp.diff(e, n) * dn(th)
+        if var is v:
+            return sp.diff(e, v) + sp.diff(e, tv) * (1 - tv**2) * ivm + sp.diff(e, n) * dn(v)
+        return sp.diff(e, w) + sp.diff(e, n) * dn(w)
+
+    Ja = sp.Matrix(2, 4, lambda r, k: total(acc[r], (bx, th, v, w)[k]))
+    Jua = sp.Matrix([sp.diff(acc[0], u), sp.diff(acc[1], u)])
+    return dict(prm=list(prm), state=[bx, th, v, w], u=u, ext=[fbx, fmx, fmy], acc=acc, Ja=Ja, Jua=Jua,
+                helpers=dict(s=s, c=c, tv=tv, n=n, inv_n=inv_n, sr=sr, sl=sl, on_r=on_r, on_l=on_l, ivm=ivm),
+                vx=vx, vy=vy)
+
+
+def emit_single(model, scalar, with_ext):
+    """One function: consts (parameter-only temporaries, evaluated by single_pendulum_gen_consts) + per-lane code."""
+    h = model["helpers"]
+    prm = model["prm"]
+    sub_ext = {} if with_ext else {e: 0 for e in model["ext"]}
+    outs = [("a[0]", model["acc"][0]), ("a[1]", model["acc"][1])]
+    for r in range(2):
+        for k in range(4):
+            outs.append(("Ja[%d][%d]" % (r, k), model["Ja"][r, k]))
+    outs += [("Jua[0]", model["Jua"][0]), ("Jua[1]", model["Jua"][1])]
+    n2 = model["vx"]**2 + model["vy"]**2
+    exprs = [sp.together(e.subs(sub_ext)) if i >= 2 else e.subs(sub_ext) for i, (_, e) in enumerate(outs)] + [n2]
+    repl, red = sp.cse(exprs, symbols=sp.numbered_symbols("t"), optimizations="basic")
+    pset = set(prm) | {h["ivm"]}
+    const_syms, lane = [], []
+    for sym, e in repl:   # a temporary that depends on parameters (and earlier constants) only is a constant
+        if e.free_symbols <= (pset | set(const_syms)):
+            const_syms.append(sym)
+        lane.append((sym, e))
+    return outs, repl, red, const_syms
+
+
+def _c_expr(pr, e):
+    return pr.doprint(e)
+
+
+def write_single(model):
+    h = model["helpers"]
+    files = {}
+    for lang in ("c", "hip"):
+        scalar = "double" if lang == "c" else "R"
+        pr = _Printer(scalar)
+        lines = ["// GENERATED by tools/gen_dynamics.py from the Lagrangian of symbolic/dynamics_single.py:58-143 -- do not edit.",
+                 "// Accelerations a = (b_x'', th_1''), Ja = da/d(b_x, th_1, b_x', th_1') (2x4), Jua = da/du (2); the full",
+                 "// state derivative is (b_x', th_1', a) and its Jacobian [[0 0 1 0],[0 0 0 1],[Ja]]",
+                 "// (single_pendulum_dynamics.hpp:159-166).  p = {m_b, m_1, l_1, g, mu_b, v_mu_b, c_d_1, x_s, k_s}."]
+        variants = {}
+        for with_ext in (False, True):
+            variants[with_ext] = emit_single(model, scalar, with_ext)
+        # constants: union over both variants, evaluated from the raw parameters
+        if lang == "hip":
+            lines += ["#pragma once", "namespace cpmpc {"]
+        for with_ext in (False, True):
+            outs, repl, red, const_syms = variants[with_ext]
+            tag = "ext" if with_ext else "noext"
+            nk = len(const_syms)
+            cdecl = "SinglePendulumGenConsts_%s" % tag
+            if lang == "hip":
+                lines += ["template <typename R>", "struct %s {" % cdecl, "  R p[9], ivm, tanh_k2;", "  R k[%d];" % max(nk, 1), "};",
+                          "template <typename R, typename P>",
+                          "__host__ __device__ inline %s<R> single_pendulum_gen_consts_%s(const P* q) {" % (cdecl, tag),
+                          "  %s<R> K;" % cdecl]
+                ctype = "P"
+            else:
+                lines += ["typedef struct { double p[9], ivm; double k[%d]; } %s;" % (max(nk, 1), cdecl),
+                          "static %s single_pendulum_gen_consts_%s(const double* q) {" % (cdecl, tag), "  %s K;" % cdecl]
+                ctype = "double"
+            prc = _Printer(ctype)
+            for i, sym in enumerate(model["prm"]):
+                lines.append("  const %s %s = q[%d];" % (ctype, sym, i))
+            lines.append("  const %s ivm = %s(1) / ((%s(1.0e-6) < v_mu_b) ? v_mu_b : %s(1.0e-6));" % ((ctype,) * 4) if lang == "hip" else
+                         "  const double ivm = 1.0 / ((1.0e-6 < v_mu_b) ? v_mu_b : 1.0e-6);")
+            for sym, e in repl:
+                if sym in const_syms:
+                    lines.append("  const %s %s = %s;" % (ctype, sym, prc.doprint(e)))
+            cast = "R" if lang == "hip" else ""
+            lines.append("  for (int i = 0; i < 9; ++i) K.p[i] = %s(q[i]);" % cast if lang == "hip" else "  for (int i = 0; i < 9; ++i) K.p[i] = q[i];")
+            lines.append("  K.ivm = %s(ivm);" % cast if lang == "hip" else "  K.ivm = ivm;")
+            if lang == "hip":
+                lines.append("  K.tanh_k2 = R(P(-2.8853900817779268) * ivm);  // fp32 tanh: exp2 argument scale")
+            for i, sym in enumerate(const_syms):
+                lines.append("  K.k[%d] = %s(%s);" % (i, cast, sym) if lang == "hip" else "  K.k[%d] = %s;" % (i, sym))
+            lines += ["  return K;", "}"]
+            # per-lane function
+            if lang == "hip":
+                lines += ["template <typename R, bool WITH_J>",
+                          "__device__ __forceinline__ void single_pendulum_gen_accel_%s(const %s<R>& K, const R b_x, const R th_1, "
+                          "const R b_x_dot, const R th_1_dot, const R u, const R f_b_x, const R f_m1_x, const R f_m1_y, "
+                          "R (&a)[2], R (&Ja)[2][4], R (&Jua)[2]) {" % (tag, cdecl)]
+            else:
+                lines += ["static void single_pendulum_gen_accel_%s(const %s* Kp, double b_x, double th_1, double b_x_dot, "
+                          "double th_1_dot, double u, double f_b_x, double f_m1_x, double f_m1_y, double a[2], double Ja[2][4], "
+                          "double Jua[2], int WITH_J) {" % (tag, cdecl), "  const %s K = *Kp;" % cdecl]
+            for i, sym in enumerate(model["prm"]):
+                lines.append("  const %s %s = K.p[%d];" % (scalar, sym, i))
+            for i, sym in enumerate(const_syms):
+                lines.append("  const %s %s = K.k[%d];" % (scalar, sym, i))
+            lines.append("  const %s ivm = K.ivm;" % scalar)
+            if lang == "hip":
+                lines += ["  R s, c;", "  Math<R>::sincos(th_1, s, c);",
+                          "  const R tv = Math<R>::tanh_scaled(b_x_dot, ivm, K.tanh_k2);"]
+            else:
+                lines += ["  const double s = sin(th_1), c = cos(th_1);", "  const double tv = tanh(b_x_dot * ivm);"]
+            z, one = ("%s(0)" % scalar, "%s(1)" % scalar) if lang == "hip" else ("0.0", "1.0")
+            lines += ["  const %s e_r = b_x - x_s, e_l = -x_s - b_x;          // strict comparisons, as the generated branches" % scalar,
+                      "  const bool is_r = %s < e_r, is_l = %s < e_l;" % (z, z),
+                      "  const %s sr = is_r ? e_r : %s, sl = is_l ? e_l : %s;" % (scalar, z, z),
+                      "  const %s on_r = is_r ? %s : %s, on_l = is_l ? %s : %s;" % (scalar, one, z, one, z)]
+            # n2 is the last reduced expression; its temporaries come first in repl order, so emit everything in order and
+            # compute n, inv_n as soon as n2's dependencies are available: simplest is to emit n2 from scratch
+            vx, vy = model["vx"], model["vy"]
+            lines.append("  const %s n2 = %s;" % (scalar, pr.doprint(vx**2 + vy**2)))
+            if lang == "hip":
+                lines += ["  R n, inv_n;", "  Math<R>::sqrt_inv(n2, n, inv_n);"]
+            else:
+                lines += ["  const double n = sqrt(n2);", "  const double inv_n = (0.0 < n2) ? 1.0 / n : 0.0;"]
+            # which temporaries do the value outputs need?
+            need = set()
+            dep = {sym: e.free_symbols for sym, e in repl}
+            stack = list(red[0].free_symbols | red[1].free_symbols)
+            while stack:
+                t = stack.pop()
+                if t in dep and t not in need:
+                    need.add(t)
+                    stack.extend(dep[t])
+            for sym, e in repl:
+                if sym in const_syms or sym not in need:
+                    continue
+                lines.append("  const %s %s = %s;" % (scalar, sym, pr.doprint(e)))
+            lines.append("  a[0] = %s;" % pr.doprint(red[0]))
+            lines.append("  a[1] = %s;" % pr.doprint(red[1]))
+            lines.append("  if (WITH_J) {")
+            for sym, e in repl:
+                if sym in const_syms or sym in need:
+                    continue
+                if sym in red[-1].free_symbols and not any(sym in r.free_symbols for r in red[:-1]) and \
+                        not any(sym in e2.free_symbols for s2, e2 in repl if s2 is not sym):
+                    continue   # used by the n2 output only
+                lines.append("    const %s %s = %s;" % (scalar, sym, pr.doprint(e)))
+            for (name, _), e in zip(outs[2:], red[2:-1]):
+                lines.append("    %s = %s;" % (name, pr.doprint(e)))
+            lines += ["  }", "  (void)th_1; (void)n; (void)inv_n; (void)on_r; (void)on_l; (void)f_b_x; (void)f_m1_x; (void)f_m1_y; (void)Ja; (void)Jua;", "}"]
+        if lang == "hip":
+            lines.append("}  // namespace cpmpc")
+        files[lang] = "\n".join(lines) + "\n"
+    with open(os.path.join(ROOT, "oracle", "single_pendulum_gen.inc"), "w") as fh:
+        fh.write(files["c"])
+    with open(os.path.join(ROOT, "cart-pole-mpc_amd", "csrc", "single_pendulum_gen.hpp"), "w") as fh:
+        fh.write(files["hip"])
+    return files
+
+
+
 def main():
     model = derive_double()
     banner = ["// GENERATED by tools/gen_dynamics.py from the Lagrangian of symbolic/dynamics_double.py:25-107 -- do not edit.",
@@ -153,6 +377,11 @@ def main():
     hip = emit(model, "R", banner + ["#pragma once", "namespace cpmpc {"]) + "}  // namespace cpmpc\n"
     with open(os.path.join(ROOT, "cart-pole-mpc_amd", "csrc", "double_pendulum_gen.hpp"), "w") as fh:
         fh.write(hip)
+    single = derive_single()
+    files = write_single(single)
+    print("single pendulum: a0 =", sp.simplify(single["acc"][0]))
+    print("wrote oracle/single_pendulum_gen.inc (%d lines), csrc/single_pendulum_gen.hpp (%d lines)"
+          % (files["c"].count("\n"), files["hip"].count("\n")))
     print("M =", model["M"])
     print("F =", model["F"])
     print("wrote oracle/double_pendulum_gen.inc (%d lines), csrc/double_pendulum_gen.hpp" % c_code.count("\n"))
