@@ -47,6 +47,24 @@ def build_lib(force=False, verbose=False):
         return _compile(verbose)
 
 
+def build_variant(name, flags, force=False, verbose=False):
+    """The same library with extra hipcc flags, in tools/_build/lib_<name>/ (used through CPMPC_LIB=<path>):
+    `generated` = -DCPMPC_GENERATED_SINGLE=1 (kernels on the generated single-pendulum dynamics),
+    `timing` = -DCPMPC_FUSED_TIMING (per-phase shader-clock counters, tools/phase_timing.py)."""
+    out = os.path.join(HERE, "..", "tools", "_build", "lib_" + name, "libcpmpc.so")
+    out = os.path.abspath(out)
+    if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in _deps()):
+        return out
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC"] + \
+        list(flags) + ["-o", out + ".tmp"] + SOURCES
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    os.replace(out + ".tmp", out)
+    return out
+
+
 def _compile(verbose):
     # -fno-slp-vectorize: on gfx950 a v_pk_fma_f32 issues at ~1.8x the cost of a v_fma_f32 (tools/ubench/pk.hip),
     # so the SLP vectoriser's packing plus its pairing moves is a net loss here (measured 91M -> 104M re-plans/s,
@@ -114,3 +132,5 @@ def build_host(force=False, verbose=False):
 if __name__ == "__main__":
     print(build_lib(force="--force" in sys.argv, verbose=True))
     print(build_host(force="--force" in sys.argv, verbose=True))
+    if "--variants" in sys.argv:
+        print(build_variant("generated", ["-DCPMPC_GENERATED_SINGLE=1"], verbose=True))

@@ -11,6 +11,15 @@
 
 #include "cartpole_device.hpp"
 #include "double_pendulum_gen.hpp"
+#include "single_pendulum_gen.hpp"
+
+// 1: the single-pole kernels are built on the code tools/gen_dynamics.py emits (single_pendulum_gen.hpp) instead of the
+// hand-written cartpole_accel.  Same results to 1e-12 (tests/test_generated_dynamics.py); the generated form evaluates
+// the closed-form 2x2 inverse and its symbolic derivatives like the reference's generator does and costs more
+// instructions, so the hand-written one stays the default.
+#ifndef CPMPC_GENERATED_SINGLE
+#define CPMPC_GENERATED_SINGLE 0
+#endif
 
 namespace cpmpc {
 
@@ -18,7 +27,7 @@ namespace cpmpc {
 // cart + single pole: gen::single_pendulum_dynamics (single_pendulum_dynamics.hpp:13-186)
 // ------------------------------------------------------------------------------------------------
 template <typename R>
-struct SingleModel {
+struct SingleModelHandWritten {
   static constexpr int NX = 4, NQ = 2, NP = 9;
   using Consts = CartPoleConsts<R>;
   template <typename P>
@@ -32,6 +41,35 @@ struct SingleModel {
     cartpole_accel<R, WITH_J, HAS_EXT>(k, x[0], x[1], x[2], x[3], u, fe, a[0], a[1], Ja, Jua);
   }
 };
+
+// the same model on the generated code (README.md:60-71 "Changing the dynamics": edit the Lagrangian in
+// tools/gen_dynamics.py, run it, rebuild with -DCPMPC_GENERATED_SINGLE=1)
+template <typename R>
+struct SingleModelGenerated {
+  static constexpr int NX = 4, NQ = 2, NP = 9;
+  using Consts = SinglePendulumGenConsts<R>;
+  template <typename P>
+  __host__ __device__ static Consts make(const P* p) {
+    return single_pendulum_gen_consts<R, P>(p);
+  }
+  template <bool WITH_J, bool HAS_EXT>
+  __device__ __forceinline__ static void accel(const Consts& k, const R (&x)[NX], const R u,
+                                               const ExtForce<R>& fe, R (&a)[NQ], R (&Ja)[NQ][NX],
+                                               R (&Jua)[NQ]) {
+    if constexpr (HAS_EXT)
+      single_pendulum_gen_accel_ext<R, WITH_J>(k, x[0], x[1], x[2], x[3], u, fe.fbx, fe.fmx, fe.fmy, a, Ja, Jua);
+    else
+      single_pendulum_gen_accel_noext<R, WITH_J>(k, x[0], x[1], x[2], x[3], u, R(0), R(0), R(0), a, Ja, Jua);
+  }
+};
+
+#if CPMPC_GENERATED_SINGLE
+template <typename R>
+using SingleModel = SingleModelGenerated<R>;
+#else
+template <typename R>
+using SingleModel = SingleModelHandWritten<R>;
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // cart + double pole: symbolic/dynamics_double.py:25-148 (generated terms, numeric 3x3 solve)

@@ -183,6 +183,43 @@ void orc_dynamics(const double params[9], const double x[4], double u, const dou
   }
 }
 
+/* The same function as emitted by this repo's dynamics generator (tools/gen_dynamics.py: SymPy Lagrangian of
+ * symbolic/dynamics_single.py:58-143 -> CSE'd straight-line code).  Exposed so that the tests hold the generated
+ * model against the hand-written one above and against the golden vectors; nothing else in the oracle uses it. */
+#include "single_pendulum_gen.inc" /* generated by tools/gen_dynamics.py */
+
+void orc_dynamics_generated(const double params[9], const double x[4], double u, const double f_base[2],
+                            const double f_mass[2], double f_out[4], double* Jx, double* Ju) {
+  const SinglePendulumGenConsts K = single_pendulum_gen_consts(params);
+  double a[2], Ja[2][4], Jua[2];
+  const int want_j = (Jx != NULL) || (Ju != NULL);
+  if (f_base != NULL || f_mass != NULL) {
+    const double fbx = f_base ? f_base[0] : 0.0, fmx = f_mass ? f_mass[0] : 0.0, fmy = f_mass ? f_mass[1] : 0.0;
+    single_pendulum_gen_accel_ext(&K, x[0], x[1], x[2], x[3], u, fbx, fmx, fmy, a, Ja, Jua, want_j);
+  } else {
+    single_pendulum_gen_accel_noext(&K, x[0], x[1], x[2], x[3], u, 0.0, 0.0, 0.0, a, Ja, Jua, want_j);
+  }
+  f_out[0] = x[2];
+  f_out[1] = x[3];
+  f_out[2] = a[0];
+  f_out[3] = a[1];
+  if (Jx) {
+    for (int i = 0; i < 16; ++i) Jx[i] = 0.0;
+    Jx[0 * 4 + 2] = 1.0; /* single_pendulum_dynamics.hpp:159-166 */
+    Jx[1 * 4 + 3] = 1.0;
+    for (int k = 0; k < 4; ++k) {
+      Jx[2 * 4 + k] = Ja[0][k];
+      Jx[3 * 4 + k] = Ja[1][k];
+    }
+  }
+  if (Ju) {
+    Ju[0] = 0.0;
+    Ju[1] = 0.0;
+    Ju[2] = Jua[0];
+    Ju[3] = Jua[1];
+  }
+}
+
 /* ------------------------------------------------------------------------------------------- */
 /* L0 (second model): cart + double pendulum                                                     */
 /* ------------------------------------------------------------------------------------------- */

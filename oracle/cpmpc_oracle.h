@@ -113,6 +113,9 @@ void orc_default_solver_opts(orc_solver_opts* o);
  * x = {b_x, th_1, b_x_dot, th_1_dot}.  Jx is 4x4 row-major, Ju is 4; either may be NULL. */
 void orc_dynamics(const double params[9], const double x[4], double u, const double f_base[2],
                   const double f_mass[2], double f_out[4], double* Jx, double* Ju);
+/* the same, evaluated by the code tools/gen_dynamics.py generates (oracle/single_pendulum_gen.inc) */
+void orc_dynamics_generated(const double params[9], const double x[4], double u, const double f_base[2],
+                            const double f_mass[2], double f_out[4], double* Jx, double* Ju);
 
 void orc_rk4(const double params[9], const double x[4], double u, double h,
              const double f_base[2], const double f_mass[2], double x_new[4], double A[16],

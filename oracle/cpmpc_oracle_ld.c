@@ -24,6 +24,7 @@
 #define orc_default_opt_params orcld_default_opt_params
 #define orc_default_solver_opts orcld_default_solver_opts
 #define orc_dynamics orcld_dynamics
+#define orc_dynamics_generated orcld_dynamics_generated
 #define orc_dynamics_double orcld_dynamics_double
 #define orc_energy_double orcld_energy_double
 #define orc_mod_pi orcld_mod_pi

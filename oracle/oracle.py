@@ -16,10 +16,10 @@ _LIB_LD_PATH = os.path.join(_HERE, "libcpmpc_oracle_ld.so")
 
 def build(force=False):
     """Compile the oracle with gcc (seconds)."""
-    src = os.path.join(_HERE, "cpmpc_oracle.c")
-    hdr = os.path.join(_HERE, "cpmpc_oracle.h")
+    srcs = [os.path.join(_HERE, f) for f in ("cpmpc_oracle.c", "cpmpc_oracle.h", "single_pendulum_gen.inc",
+                                             "double_pendulum_gen.inc")]
     if (not force and os.path.exists(_LIB_PATH)
-            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(f) for f in srcs)):
         return _LIB_PATH
     subprocess.check_call(["make", "-C", _HERE, "-B", "libcpmpc_oracle.so"],
                           stdout=subprocess.DEVNULL)
@@ -129,6 +129,7 @@ def lib():
     L.orc_default_opt_params.argtypes = [C.POINTER(OptParams)]
     L.orc_default_solver_opts.argtypes = [C.POINTER(SolverOpts)]
     L.orc_dynamics.argtypes = [_dp, _dp, C.c_double, _dp, _dp, _dp, _dp, _dp]
+    L.orc_dynamics_generated.argtypes = [_dp, _dp, C.c_double, _dp, _dp, _dp, _dp, _dp]
     L.orc_rk4.argtypes = [_dp, _dp, C.c_double, C.c_double, _dp, _dp, _dp, _dp, _dp]
     L.orc_rk4_no_jacobians.argtypes = [_dp, _dp, C.c_double, C.c_double, _dp, _dp, _dp]
     L.orc_mod_pi.argtypes = [C.c_double]
@@ -230,6 +231,18 @@ def dynamics(params, x, u, f_base=None, f_mass=None, jacobians=True):
         return f, Jx, Ju
     lib().orc_dynamics(_ptr(params), _ptr(x), float(u), _ptr(fb), _ptr(fm), _ptr(f), None, None)
     return f
+
+
+def dynamics_generated(params, x, u, f_base=None, f_mass=None, jacobians=True):
+    """orc_dynamics_generated: the code emitted by tools/gen_dynamics.py (forces None -> the specialisation generated
+    without external forces)."""
+    params, x = _vec(params, 9), _vec(x, 4)
+    fb = None if f_base is None and f_mass is None else _vec(_Z2 if f_base is None else f_base, 2)
+    fm = None if f_base is None and f_mass is None else _vec(_Z2 if f_mass is None else f_mass, 2)
+    f = np.zeros(4)
+    Jx, Ju = (np.zeros((4, 4)), np.zeros(4)) if jacobians else (None, None)
+    lib().orc_dynamics_generated(_ptr(params), _ptr(x), float(u), _ptr(fb), _ptr(fm), _ptr(f), _ptr(Jx), _ptr(Ju))
+    return (f, Jx, Ju) if jacobians else f
 
 
 def rk4(params, x, u, h, f_base=None, f_mass=None):

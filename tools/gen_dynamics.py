@@ -103,7 +103,7 @@ class _Printer(C99CodePrinter):
             b = self._print(e.base)
             if not e.base.is_Atom:
                 b = "(" + b + ")"
-            return "*".join([b] * int(e.exp))
+            return "(" + "*".join([b] * int(e.exp)) + ")"   # parenthesised: it may sit in a denominator
         return super()._print_Pow(e)
 
     def _print_Float(self, e):
@@ -114,6 +114,8 @@ class _Printer(C99CodePrinter):
         return "%s(%d)" % (self.scalar, int(e)) if self.scalar != "double" else "%d.0" % int(e)
 
     def _print_Rational(self, e):
+        if self.scalar == "double":
+            return "(%d.0/%d.0)" % (e.p, e.q)
         return "(%s(%d)/%s(%d))" % (self.scalar, e.p, self.scalar, e.q)
 
 
@@ -223,89 +225,135 @@ def derive_single():
                 vx=vx, vy=vy)
 
 
-def emit_single(model, scalar, with_ext):
-    """One function: consts (parameter-only temporaries, evaluated by single_pendulum_gen_consts) + per-lane code."""
-    h = model["helpers"]
-    prm = model["prm"]
-    sub_ext = {} if with_ext else {e: 0 for e in model["ext"]}
+def cse_single(model):
+    """One common-subexpression pass over everything the function returns (with the external forces in)."""
     outs = [("a[0]", model["acc"][0]), ("a[1]", model["acc"][1])]
     for r in range(2):
         for k in range(4):
-            outs.append(("Ja[%d][%d]" % (r, k), model["Ja"][r, k]))
+            outs.append(("Ja[%d][%d]" % (r, k), sp.together(model["Ja"][r, k])))
     outs += [("Jua[0]", model["Jua"][0]), ("Jua[1]", model["Jua"][1])]
-    n2 = model["vx"]**2 + model["vy"]**2
-    exprs = [sp.together(e.subs(sub_ext)) if i >= 2 else e.subs(sub_ext) for i, (_, e) in enumerate(outs)] + [n2]
-    repl, red = sp.cse(exprs, symbols=sp.numbered_symbols("t"), optimizations="basic")
-    pset = set(prm) | {h["ivm"]}
-    const_syms, lane = [], []
-    for sym, e in repl:   # a temporary that depends on parameters (and earlier constants) only is a constant
-        if e.free_symbols <= (pset | set(const_syms)):
-            const_syms.append(sym)
-        lane.append((sym, e))
-    return outs, repl, red, const_syms
+    repl, red = sp.cse([e for _, e in outs], symbols=sp.numbered_symbols("t"), optimizations="basic")
+    return [n for n, _ in outs], repl, red
 
 
-def _c_expr(pr, e):
-    return pr.doprint(e)
+def specialise(model, repl, red, with_ext):
+    """The temporaries and outputs with the external forces present or identically zero (forward-substituting what
+    collapses to a number), split into: parameter-only constants / needed by the accelerations / needed by the
+    Jacobians only."""
+    zero = {} if with_ext else {e: 0 for e in model["ext"]}
+    known, lane = {}, []
+    for sym, e in repl:
+        e2 = e.subs(zero).subs(known)
+        if e2.is_Number or e2.is_Symbol:
+            known[sym] = e2
+        else:
+            lane.append((sym, e2))
+    red2 = [e.subs(zero).subs(known) for e in red]
+    pset = set(model["prm"]) | {model["helpers"]["ivm"]}
+    consts = []
+    for sym, e in lane:
+        if e.free_symbols <= (pset | set(consts)):
+            consts.append(sym)
+    # hoist the parameter-only factors that CSE left inside per-lane products (g*m_b*(mu_b*tv) -> k*tv, 1/l_1, ...)
+    hoisted = model.setdefault("_hoisted", {})   # expression -> constant symbol, shared by both specialisations
+
+    def is_const(e):
+        return e.free_symbols <= (pset | set(consts))
+
+    def hoist(e):
+        if e.is_Atom:
+            return e
+        args = [hoist(a) for a in e.args]
+        if e.is_Mul:
+            cpart = [a for a in args if is_const(a)]
+            rest = [a for a in args if not is_const(a)]
+            nontrivial = [a for a in cpart if not a.is_Number]
+            if rest and (len(nontrivial) >= 2 or any(not a.is_Atom for a in nontrivial)):
+                ce = sp.Mul(*cpart)
+                if ce not in hoisted:
+                    hoisted[ce] = sp.Symbol("kc%d" % len(hoisted), real=True)
+                return sp.Mul(hoisted[ce], *rest)
+        if e.is_Pow and is_const(e.base) and not e.base.is_Number and e.exp.is_Number and e.exp < 0:
+            if e not in hoisted:
+                hoisted[e] = sp.Symbol("kc%d" % len(hoisted), real=True)
+            return hoisted[e]
+        return e.func(*args)
+
+    lane = [(sym, e if sym in consts else hoist(e)) for sym, e in lane]
+    red2 = [hoist(e) for e in red2]
+    dep = {sym: e.free_symbols for sym, e in lane}
+
+    def closure(exprs):
+        need, stack = set(), [t for e in exprs for t in e.free_symbols]
+        while stack:
+            t = stack.pop()
+            if t in dep and t not in need:
+                need.add(t)
+                stack.extend(dep[t])
+        return need
+
+    need_a = closure(red2[:2])
+    need_j = closure(red2[2:]) - need_a
+    return lane, red2, consts, need_a, need_j
 
 
 def write_single(model):
-    h = model["helpers"]
+    names, repl, red = cse_single(model)
+    # the constants of the two specialisations are the same parameter-only temporaries: take the union, in CSE order
+    spec = {w: specialise(model, repl, red, w) for w in (False, True)}
+    const_syms = [sym for sym, _ in repl if any(sym in spec[w][2] for w in (False, True))]
+    const_expr = dict(repl)
+    for ce, sym in model.get("_hoisted", {}).items():   # the hoisted parameter-only factors come after the CSE constants
+        const_syms.append(sym)
+        const_expr[sym] = ce
+    vx, vy = model["vx"], model["vy"]
     files = {}
     for lang in ("c", "hip"):
         scalar = "double" if lang == "c" else "R"
         pr = _Printer(scalar)
+        z, one = ("%s(0)" % scalar, "%s(1)" % scalar) if lang == "hip" else ("0.0", "1.0")
         lines = ["// GENERATED by tools/gen_dynamics.py from the Lagrangian of symbolic/dynamics_single.py:58-143 -- do not edit.",
                  "// Accelerations a = (b_x'', th_1''), Ja = da/d(b_x, th_1, b_x', th_1') (2x4), Jua = da/du (2); the full",
                  "// state derivative is (b_x', th_1', a) and its Jacobian [[0 0 1 0],[0 0 0 1],[Ja]]",
-                 "// (single_pendulum_dynamics.hpp:159-166).  p = {m_b, m_1, l_1, g, mu_b, v_mu_b, c_d_1, x_s, k_s}."]
-        variants = {}
-        for with_ext in (False, True):
-            variants[with_ext] = emit_single(model, scalar, with_ext)
-        # constants: union over both variants, evaluated from the raw parameters
+                 "// (single_pendulum_dynamics.hpp:159-166).  p = {m_b, m_1, l_1, g, mu_b, v_mu_b, c_d_1, x_s, k_s};",
+                 "// k[] = the parameter-only sub-expressions, evaluated once (on the host, in double) by ..._consts()."]
+        nk = max(len(const_syms), 1)
         if lang == "hip":
-            lines += ["#pragma once", "namespace cpmpc {"]
+            ctype, prc = "P", _Printer("P")
+            lines += ["#pragma once", "namespace cpmpc {", "template <typename R>", "struct SinglePendulumGenConsts {",
+                      "  R p[9], ivm, tanh_k2;", "  R k[%d];" % nk, "};", "template <typename R, typename P>",
+                      "__host__ __device__ inline SinglePendulumGenConsts<R> single_pendulum_gen_consts(const P* q) {",
+                      "  SinglePendulumGenConsts<R> K;"]
+        else:
+            ctype, prc = "double", _Printer("double")
+            lines += ["typedef struct { double p[9], ivm; double k[%d]; } SinglePendulumGenConsts;" % nk,
+                      "static SinglePendulumGenConsts single_pendulum_gen_consts(const double* q) {", "  SinglePendulumGenConsts K;"]
+        for i, sym in enumerate(model["prm"]):
+            lines.append("  const %s %s = q[%d];" % (ctype, sym, i))
+        lines.append("  const {0} ivm = {0}(1) / (({0}(1.0e-6) < v_mu_b) ? v_mu_b : {0}(1.0e-6));".format(ctype) if lang == "hip"
+                     else "  const double ivm = 1.0 / ((1.0e-6 < v_mu_b) ? v_mu_b : 1.0e-6);  /* max(v_mu_b, 1e-6) */")
+        for sym in const_syms:
+            lines.append("  const %s %s = %s;" % (ctype, sym, prc.doprint(const_expr[sym])))
+        cast = "R" if lang == "hip" else ""
+        lines.append("  for (int i = 0; i < 9; ++i) K.p[i] = %s(q[i]);" % cast)
+        lines.append("  K.ivm = %s(ivm);" % cast)
+        if lang == "hip":
+            lines.append("  K.tanh_k2 = R(P(-2.8853900817779268) * ivm);  // fp32 tanh: exp2 argument scale")
+        for i, sym in enumerate(const_syms):
+            lines.append("  K.k[%d] = %s(%s);" % (i, cast, sym))
+        lines += ["  (void)m_b; (void)m_1; (void)l_1; (void)g; (void)mu_b; (void)c_d_1; (void)x_s; (void)k_s;", "  return K;", "}"]
         for with_ext in (False, True):
-            outs, repl, red, const_syms = variants[with_ext]
+            lane, red2, consts, need_a, need_j = spec[with_ext]
             tag = "ext" if with_ext else "noext"
-            nk = len(const_syms)
-            cdecl = "SinglePendulumGenConsts_%s" % tag
-            if lang == "hip":
-                lines += ["template <typename R>", "struct %s {" % cdecl, "  R p[9], ivm, tanh_k2;", "  R k[%d];" % max(nk, 1), "};",
-                          "template <typename R, typename P>",
-                          "__host__ __device__ inline %s<R> single_pendulum_gen_consts_%s(const P* q) {" % (cdecl, tag),
-                          "  %s<R> K;" % cdecl]
-                ctype = "P"
-            else:
-                lines += ["typedef struct { double p[9], ivm; double k[%d]; } %s;" % (max(nk, 1), cdecl),
-                          "static %s single_pendulum_gen_consts_%s(const double* q) {" % (cdecl, tag), "  %s K;" % cdecl]
-                ctype = "double"
-            prc = _Printer(ctype)
-            for i, sym in enumerate(model["prm"]):
-                lines.append("  const %s %s = q[%d];" % (ctype, sym, i))
-            lines.append("  const %s ivm = %s(1) / ((%s(1.0e-6) < v_mu_b) ? v_mu_b : %s(1.0e-6));" % ((ctype,) * 4) if lang == "hip" else
-                         "  const double ivm = 1.0 / ((1.0e-6 < v_mu_b) ? v_mu_b : 1.0e-6);")
-            for sym, e in repl:
-                if sym in const_syms:
-                    lines.append("  const %s %s = %s;" % (ctype, sym, prc.doprint(e)))
-            cast = "R" if lang == "hip" else ""
-            lines.append("  for (int i = 0; i < 9; ++i) K.p[i] = %s(q[i]);" % cast if lang == "hip" else "  for (int i = 0; i < 9; ++i) K.p[i] = q[i];")
-            lines.append("  K.ivm = %s(ivm);" % cast if lang == "hip" else "  K.ivm = ivm;")
-            if lang == "hip":
-                lines.append("  K.tanh_k2 = R(P(-2.8853900817779268) * ivm);  // fp32 tanh: exp2 argument scale")
-            for i, sym in enumerate(const_syms):
-                lines.append("  K.k[%d] = %s(%s);" % (i, cast, sym) if lang == "hip" else "  K.k[%d] = %s;" % (i, sym))
-            lines += ["  return K;", "}"]
-            # per-lane function
             if lang == "hip":
                 lines += ["template <typename R, bool WITH_J>",
-                          "__device__ __forceinline__ void single_pendulum_gen_accel_%s(const %s<R>& K, const R b_x, const R th_1, "
-                          "const R b_x_dot, const R th_1_dot, const R u, const R f_b_x, const R f_m1_x, const R f_m1_y, "
-                          "R (&a)[2], R (&Ja)[2][4], R (&Jua)[2]) {" % (tag, cdecl)]
+                          "__device__ __forceinline__ void single_pendulum_gen_accel_%s(const SinglePendulumGenConsts<R>& K, const R b_x, "
+                          "const R th_1, const R b_x_dot, const R th_1_dot, const R u, const R f_b_x, const R f_m1_x, "
+                          "const R f_m1_y, R (&a)[2], R (&Ja)[2][4], R (&Jua)[2]) {" % tag]
             else:
-                lines += ["static void single_pendulum_gen_accel_%s(const %s* Kp, double b_x, double th_1, double b_x_dot, "
-                          "double th_1_dot, double u, double f_b_x, double f_m1_x, double f_m1_y, double a[2], double Ja[2][4], "
-                          "double Jua[2], int WITH_J) {" % (tag, cdecl), "  const %s K = *Kp;" % cdecl]
+                lines += ["static void single_pendulum_gen_accel_%s(const SinglePendulumGenConsts* Kp, double b_x, double th_1, "
+                          "double b_x_dot, double th_1_dot, double u, double f_b_x, double f_m1_x, double f_m1_y, double a[2], "
+                          "double Ja[2][4], double Jua[2], int WITH_J) {" % tag, "  const SinglePendulumGenConsts K = *Kp;"]
             for i, sym in enumerate(model["prm"]):
                 lines.append("  const %s %s = K.p[%d];" % (scalar, sym, i))
             for i, sym in enumerate(const_syms):
@@ -314,47 +362,32 @@ def write_single(model):
             if lang == "hip":
                 lines += ["  R s, c;", "  Math<R>::sincos(th_1, s, c);",
                           "  const R tv = Math<R>::tanh_scaled(b_x_dot, ivm, K.tanh_k2);"]
+                boolt = "bool"
             else:
                 lines += ["  const double s = sin(th_1), c = cos(th_1);", "  const double tv = tanh(b_x_dot * ivm);"]
-            z, one = ("%s(0)" % scalar, "%s(1)" % scalar) if lang == "hip" else ("0.0", "1.0")
-            lines += ["  const %s e_r = b_x - x_s, e_l = -x_s - b_x;          // strict comparisons, as the generated branches" % scalar,
-                      "  const bool is_r = %s < e_r, is_l = %s < e_l;" % (z, z),
+                boolt = "int"
+            lines += ["  const %s e_r = b_x - x_s, e_l = -x_s - b_x;  /* springs: strict comparisons, as the generated branches */" % scalar,
+                      "  const %s is_r = %s < e_r, is_l = %s < e_l;" % (boolt, z, z),
                       "  const %s sr = is_r ? e_r : %s, sl = is_l ? e_l : %s;" % (scalar, z, z),
-                      "  const %s on_r = is_r ? %s : %s, on_l = is_l ? %s : %s;" % (scalar, one, z, one, z)]
-            # n2 is the last reduced expression; its temporaries come first in repl order, so emit everything in order and
-            # compute n, inv_n as soon as n2's dependencies are available: simplest is to emit n2 from scratch
-            vx, vy = model["vx"], model["vy"]
-            lines.append("  const %s n2 = %s;" % (scalar, pr.doprint(vx**2 + vy**2)))
+                      "  const %s on_r = is_r ? %s : %s, on_l = is_l ? %s : %s;" % (scalar, one, z, one, z),
+                      "  const %s n2 = %s;  /* |p_1'|^2 */" % (scalar, pr.doprint(vx**2 + vy**2))]
             if lang == "hip":
-                lines += ["  R n, inv_n;", "  Math<R>::sqrt_inv(n2, n, inv_n);"]
+                lines += ["  R n, inv_n;", "  Math<R>::sqrt_inv(n2, n, inv_n);  // inv_n = 0 at rest: the |v|^2 > 0 guard"]
             else:
-                lines += ["  const double n = sqrt(n2);", "  const double inv_n = (0.0 < n2) ? 1.0 / n : 0.0;"]
-            # which temporaries do the value outputs need?
-            need = set()
-            dep = {sym: e.free_symbols for sym, e in repl}
-            stack = list(red[0].free_symbols | red[1].free_symbols)
-            while stack:
-                t = stack.pop()
-                if t in dep and t not in need:
-                    need.add(t)
-                    stack.extend(dep[t])
-            for sym, e in repl:
-                if sym in const_syms or sym not in need:
-                    continue
-                lines.append("  const %s %s = %s;" % (scalar, sym, pr.doprint(e)))
-            lines.append("  a[0] = %s;" % pr.doprint(red[0]))
-            lines.append("  a[1] = %s;" % pr.doprint(red[1]))
+                lines += ["  const double n = sqrt(n2);", "  const double inv_n = (0.0 < n2) ? 1.0 / n : 0.0;  /* the |v|^2 > 0 guard */"]
+            for sym, e in lane:
+                if sym in need_a and sym not in const_syms:
+                    lines.append("  const %s %s = %s;" % (scalar, sym, pr.doprint(e)))
+            lines.append("  a[0] = %s;" % pr.doprint(red2[0]))
+            lines.append("  a[1] = %s;" % pr.doprint(red2[1]))
             lines.append("  if (WITH_J) {")
-            for sym, e in repl:
-                if sym in const_syms or sym in need:
-                    continue
-                if sym in red[-1].free_symbols and not any(sym in r.free_symbols for r in red[:-1]) and \
-                        not any(sym in e2.free_symbols for s2, e2 in repl if s2 is not sym):
-                    continue   # used by the n2 output only
-                lines.append("    const %s %s = %s;" % (scalar, sym, pr.doprint(e)))
-            for (name, _), e in zip(outs[2:], red[2:-1]):
+            for sym, e in lane:
+                if sym in need_j and sym not in const_syms:
+                    lines.append("    const %s %s = %s;" % (scalar, sym, pr.doprint(e)))
+            for name, e in zip(names[2:], red2[2:]):
                 lines.append("    %s = %s;" % (name, pr.doprint(e)))
-            lines += ["  }", "  (void)th_1; (void)n; (void)inv_n; (void)on_r; (void)on_l; (void)f_b_x; (void)f_m1_x; (void)f_m1_y; (void)Ja; (void)Jua;", "}"]
+            lines += ["  }", "  (void)th_1; (void)n; (void)inv_n; (void)on_r; (void)on_l; (void)f_b_x; (void)f_m1_x; (void)f_m1_y;",
+                      "  (void)Ja; (void)Jua; (void)m_b; (void)m_1; (void)l_1; (void)g; (void)mu_b; (void)v_mu_b; (void)c_d_1; (void)k_s;", "}"]
         if lang == "hip":
             lines.append("}  // namespace cpmpc")
         files[lang] = "\n".join(lines) + "\n"
@@ -363,7 +396,6 @@ def write_single(model):
     with open(os.path.join(ROOT, "cart-pole-mpc_amd", "csrc", "single_pendulum_gen.hpp"), "w") as fh:
         fh.write(files["hip"])
     return files
-
 
 
 def main():
