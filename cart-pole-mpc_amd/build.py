@@ -112,9 +112,9 @@ def build_host(force=False, verbose=False):
 
     if stale(HOST_LIB, srcs + hdrs):
         run([cxx] + common + ["-shared", "-o", HOST_LIB] + srcs + link)
-    smoke_src = os.path.join(HOST, "host_smoke.cc")
+    smoke_src = os.path.join(HERE, "..", "tests", "host", "closed_loop_like_reference.cc")  # test infrastructure
     if stale(HOST_SMOKE, [smoke_src, HOST_LIB] + hdrs):
-        run([cxx] + common + ["-o", HOST_SMOKE, smoke_src, "-L" + LIB_DIR, "-lpendulum_host", "-lcpmpc",
+        run([cxx] + common + ["-I" + HOST, "-o", HOST_SMOKE, smoke_src, "-L" + LIB_DIR, "-lpendulum_host", "-lcpmpc",
                               "-Wl,-rpath,$ORIGIN"])
     try:
         import pybind11

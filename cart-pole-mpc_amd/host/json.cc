@@ -161,7 +161,16 @@ class Reader {
         case 't': out += '\t'; break;
         case 'u': {
           if (pos_ + 4 > s_.size()) Fail("short \\u escape");
-          const unsigned cp = static_cast<unsigned>(std::strtoul(s_.substr(pos_, 4).c_str(), nullptr, 16));
+          unsigned cp = 0;
+          for (int i = 0; i < 4; ++i) {  // exactly four hex digits (strtoul would also take signs, blanks, fewer digits)
+            const char h = s_[pos_ + static_cast<std::size_t>(i)];
+            unsigned d;
+            if (h >= '0' && h <= '9') d = static_cast<unsigned>(h - '0');
+            else if (h >= 'a' && h <= 'f') d = static_cast<unsigned>(h - 'a') + 10u;
+            else if (h >= 'A' && h <= 'F') d = static_cast<unsigned>(h - 'A') + 10u;
+            else Fail("bad \\u escape");
+            cp = cp * 16u + d;
+          }
           pos_ += 4;
           if (cp < 0x80) {
             out += static_cast<char>(cp);
@@ -179,7 +188,17 @@ class Reader {
       }
     }
   }
+  // The API structs nest three levels deep (outputs -> predicted_states[] -> state); anything much deeper is not one of
+  // them, and an unbounded recursion on "[[[[..." is a stack overflow (found by tests/host/json_fuzz.cc).
+  static constexpr int kMaxDepth = 32;
+  struct DepthGuard {
+    int& d;
+    explicit DepthGuard(int& depth) : d(depth) { ++d; }
+    ~DepthGuard() { --d; }
+  };
   Value ParseValue() {
+    const DepthGuard guard(depth_);
+    if (depth_ > kMaxDepth) Fail("nesting too deep");
     SkipSpace();
     if (pos_ >= s_.size()) Fail("unexpected end");
     Value v;
@@ -219,6 +238,11 @@ class Reader {
     } else if (c == 'n') {
       Expect("null");
     } else {
+      // a JSON number starts with '-' or a digit (strtod alone would also take "+1", "0x10", "nan", "inf", blanks)
+      if (!(c == '-' || (c >= '0' && c <= '9'))) Fail("expected a value");
+      const std::size_t digit = pos_ + (c == '-' ? 1u : 0u);
+      if (digit >= s_.size() || s_[digit] < '0' || s_[digit] > '9') Fail("expected a digit");
+      if (s_[digit] == '0' && digit + 1 < s_.size() && (s_[digit + 1] == 'x' || s_[digit + 1] == 'X')) Fail("hexadecimal number");
       const char* begin = s_.c_str() + pos_;
       char* end = nullptr;
       v.number = std::strtod(begin, &end);
@@ -231,6 +255,7 @@ class Reader {
 
   const std::string& s_;
   std::size_t pos_{0};
+  int depth_{0};
 };
 
 const Value& Member(const Value& obj, const char* key) {
@@ -247,7 +272,9 @@ double Number(const Value& v, const char* what) {
 double Number(const Value& obj, const char* key, int) { return Number(Member(obj, key), key); }
 std::size_t Index(const Value& obj, const char* key) {
   const double d = Number(obj, key, 0);
-  if (!(d >= 0.0) || d != std::floor(d)) throw std::invalid_argument(std::string("JSON: '") + key + "' is not an unsigned integer");
+  // (the upper bound keeps the conversion below defined: a double >= 2^64 cast to size_t is undefined behaviour)
+  if (!(d >= 0.0) || d != std::floor(d) || !(d <= 9007199254740992.0))
+    throw std::invalid_argument(std::string("JSON: '") + key + "' is not an unsigned integer");
   return static_cast<std::size_t>(d);
 }
 std::vector<double> NumberList(const Value& v, const char* what) {

@@ -1,6 +1,12 @@
-// host_smoke.cc -- the reference's closed-loop test (optimization/optimization_test.cc:12-77) written
-// against this repo's pendulum::Optimization / pendulum::Simulator exactly as the reference writes it
-// against its own classes.  Runs on the GPU through libcpmpc.so.  Exit code 0 = all assertions hold.
+// closed_loop_like_reference.cc -- TEST INFRASTRUCTURE: the "a caller of the reference compiles unchanged" proof.
+//
+// The body of main() below IS the reference's own closed-loop test, optimization/optimization_test.cc:12-66
+// (gareth-cross/cart-pole-mpc, MIT licence, (c) Gareth Cross): same variable names, same order of statements, same
+// tolerances, with the gtest macros replaced by CHECK_NEAR and the two #include lines pointing at this repo's
+// drop-in headers (cart-pole-mpc_amd/host/optimization.hpp, simulator.hpp).  It is kept that close on purpose: it
+// shows that code written against pendulum::Optimization / pendulum::Simulator builds and passes against this
+// repo's classes, which run on the GPU through libcpmpc.so.  Nothing in the product uses this file.
+// Built by cart-pole-mpc_amd/build.py into lib/host_smoke; run by tests/test_pypendulum.py.  Exit code 0 = all hold.
 #include <cmath>
 #include <cstdio>
 #include <vector>

@@ -14,8 +14,8 @@ LIB_DIR = os.path.join(ROOT, "cart-pole-mpc_amd", "lib")
 
 @pytest.fixture(scope="module")
 def pp():
-    import __graft_entry__
-    __graft_entry__.build()
+    import importlib
+    importlib.import_module("cart-pole-mpc_amd.build").build_host()   # libcpmpc.so + facade + module (stale-checked)
     if LIB_DIR not in sys.path:
         sys.path.insert(0, LIB_DIR)
     import pypendulum
@@ -216,7 +216,7 @@ def test_closed_loop_through_pypendulum(pp, orc):
 @pytest.mark.gpu
 def test_cpp_closed_loop_binary():
     """The reference's closed-loop gtest (optimization_test.cc:12-77) compiled against this repo's
-    pendulum::Optimization / Simulator (cart-pole-mpc_amd/host/host_smoke.cc)."""
+    pendulum::Optimization / Simulator (tests/host/closed_loop_like_reference.cc)."""
     r = subprocess.run([os.path.join(LIB_DIR, "host_smoke")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "OK closed loop" in r.stdout
