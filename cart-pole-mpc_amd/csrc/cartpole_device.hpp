@@ -170,7 +170,10 @@ struct Math<double> {
   }
 #endif
   static __device__ __forceinline__ double tanh_scaled(double x, double scale, double) { return tanh(x * scale); }
-#if CPMPC_F64_LIBM
+#ifndef CPMPC_F64_IEEE_DIV
+#define CPMPC_F64_IEEE_DIV 0  // 1: compiler-expanded IEEE division and sqrt in the fp64 kernels (A/B of the routines below)
+#endif
+#if CPMPC_F64_LIBM || CPMPC_F64_IEEE_DIV
   static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
   static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
   static __device__ __forceinline__ double div(double a, double b) { return a / b; }

@@ -535,6 +535,12 @@ static void launch_linearize(const SolverArgs<R, M>& a, int SP, const XV<R, M::N
 #undef CPMPC_LIN
 }
 
+// 1: the fp64 fused kernels also take batch-shared model constants from the kernel-argument segment (SGPRs).  Off by
+// default: see the note above launch_fused (tools/_build variant `shared64` measures it).
+#ifndef CPMPC_FUSED_SHARED_F64
+#define CPMPC_FUSED_SHARED_F64 0
+#endif
+
 // fused pipeline: compiled specialisations for these (L = S-1, SP) pairs ...
 static bool fused_static(int L, int SP) {  // the default horizon's spacings (N = 40) and N = 20
   return (L == 4 && SP == 10) || (L == 8 && SP == 5) || (L == 2 && SP == 10) || (L == 4 && SP == 5) ||
@@ -572,7 +578,7 @@ static void launch_fused(const SolverArgs<R, M>& a, int L, int SP, int max_iters
     const dim3 grid((unsigned)((a.B + ppw - 1) / ppw));
 #define CPMPC_FUSED(LV, SPV)                                                                                \
   if (L == LV && SP == SPV) {                                                                               \
-    if constexpr (sizeof(R) == 4) {                                                                         \
+    if constexpr (sizeof(R) == 4 || CPMPC_FUSED_SHARED_F64) {                                              \
       if (a.dyn == nullptr) {                                                                               \
         hipLaunchKernelGGL((fused_sqp_kernel<R, M, SPV, LV, true>), grid, dim3(64), 0, stream, a, max_iters); \
         return;                                                                                             \
@@ -593,7 +599,7 @@ static void launch_fused(const SolverArgs<R, M>& a, int L, int SP, int max_iters
     const size_t lds = fused_dyn_lds_bytes<R, M>(SP);
 #define CPMPC_FUSED_DYN(LV)                                                                                         \
   if (L == LV) {                                                                                                    \
-    if constexpr (sizeof(R) == 4) {                                                                                 \
+    if constexpr (sizeof(R) == 4 || CPMPC_FUSED_SHARED_F64) {                                                      \
       if (a.dyn == nullptr) {                                                                                       \
         hipLaunchKernelGGL((fused_sqp_dyn_kernel<R, M, LV, true>), grid, dim3(64), lds, stream, a, max_iters);      \
         return;                                                                                                     \

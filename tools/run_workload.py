@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Secondary workloads for profiling (rocprofv3 wraps this; the headline workload is bench.py itself):
+  double       BASELINE configs[4]: cart + double pendulum, B = 65536, N = 40, 5 iterations, cold start
+  closed_loop  the warm-started closed loop of SURVEY 8(f1): re-plan (reference defaults, exits enabled, staged fused
+               pipeline with compaction) + batched Simulator step, B = 262144
+usage: run_workload.py <double|closed_loop> [--dtype f32|f64] [--steps K] [--batch B]"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("cart-pole-mpc_amd")
+DYN_UI = [1.0, 0.1, 0.25, 9.81, 0.05, 0.1, 0.02, 0.8, 100.0]
+DYN_DOUBLE = [1.0, 0.1, 0.1, 0.25, 0.2, 9.81]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("workload", choices=["double", "closed_loop"])
+    ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=0)
+    a = ap.parse_args()
+    dt = torch.float32 if a.dtype == "f32" else torch.float64
+    rng = np.random.default_rng(7)
+    out = pkg.BatchOutputs()
+    if a.workload == "double":
+        B = a.batch or 65536
+        x0 = np.stack([rng.uniform(-0.3, 0.3, B), np.pi / 2 + rng.uniform(-0.15, 0.15, B), np.pi / 2 + rng.uniform(-0.15, 0.15, B),
+                       rng.uniform(-0.3, 0.3, B), rng.uniform(-0.5, 0.5, B), rng.uniform(-0.5, 0.5, B)])
+        p = pkg.default_params(max_iterations=5, relative_exit_tol=0.0, absolute_first_derivative_tol=0.0,
+                               u_guess_sinusoid_amplitude=0.0)
+        opt = pkg.BatchOptimization(p, max_batch=B, dtype=dt, device=0, model="double")
+        xt = torch.tensor(x0, dtype=dt, device="cuda:0")
+
+        def step():
+            opt.reset()
+            opt.step(xt, DYN_DOUBLE, 0.0, out=out)
+    else:
+        B = a.batch or 262144
+        xs = np.stack([rng.uniform(-0.3, 0.3, B), np.pi / 2 + rng.uniform(-0.4, 0.4, B), rng.uniform(-0.5, 0.5, B),
+                       rng.uniform(-1, 1, B)])
+        sim = pkg.BatchSimulator(B, dtype=dt, device=0)
+        sim.set_state(torch.tensor(xs, dtype=dt, device="cuda:0"))
+        opt = pkg.BatchOptimization(pkg.default_params(), max_batch=B, dtype=dt, device=0)
+
+        def step():
+            o = opt.step(sim.get_state(), DYN_UI, 0.0, want_predicted=False, want_stats=True, out=out)
+            sim.step(DYN_UI, 0.01, o.u[0].contiguous())
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    dtm = (time.perf_counter() - t0) / a.steps
+    print(json.dumps({"workload": a.workload, "dtype": a.dtype, "batch": B, "ms_per_step": dtm * 1e3,
+                      "units_per_s": B / dtm, "pipeline": opt.pipeline()}))
+
+
+if __name__ == "__main__":
+    main()

@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
-    for k in ("fused_sqp_kernel", "qp_ls_kernel", "linearize_kernel", "finalize_kernel", "prepare_kernel", "sim_kernel",
+    for k in ("fused_sqp_dyn_kernel", "fused_sqp_kernel", "compact_active_kernel", "qp_ls_kernel", "linearize_kernel", "finalize_kernel", "prepare_kernel", "sim_kernel",
               "rk4_kernel", "dynamics_kernel"):
         if k in name:
             return k
