@@ -698,7 +698,7 @@ static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* 
       a.remaining = total - done;
       span_begin(s, CPMPC_KERNEL_FUSED, stream, &sp);
       const hipError_t memset_rc = hipMemsetAsync(count, 0, sizeof(int32_t), stream);
-      hipLaunchKernelGGL(compact_active_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, stream,
+      hipLaunchKernelGGL(compact_active_kernel, dim3((unsigned)((B + 1023) / 1024)), dim3(1024), 0, stream,
                          (const int32_t*)(s->ist + (size_t)IS_STATUS * (size_t)s->cap),
                          (const int32_t*)(s->ist + (size_t)IS_ITERS * (size_t)s->cap), total, B, s->active, count);
       a.active_list = s->active;

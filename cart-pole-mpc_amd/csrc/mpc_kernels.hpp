@@ -213,17 +213,30 @@ __device__ __forceinline__ void wrap_angles(R (&x)[M::NX]) {
 // waves kept alive by one straggler.  One atomic per wave (ballot + prefix popcount); the order of the
 // list is arbitrary, which is harmless: a problem's arithmetic does not depend on where it sits.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void compact_active_kernel(const int32_t* status, const int32_t* iters,
-                                                             int iter_cap, int64_t B, int32_t* list, int32_t* count) {
+__global__ __launch_bounds__(1024) void compact_active_kernel(const int32_t* status, const int32_t* iters,
+                                                              int iter_cap, int64_t B, int32_t* list, int32_t* count) {
+  // one atomic per 1024-thread workgroup (16 waves): the wave totals go through LDS, wave 0 reserves the block's range.
+  // (One atomic per WAVE on a single counter serialised: 4096 of them took 42 us at B = 262144, profiles/r02b_closed_loop.)
+  __shared__ int wave_total[16];
+  __shared__ int block_base;
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = p < B && status[p] == kTermNone && iters[p] < iter_cap;
   const unsigned long long mask = __ballot(active);
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rank = __popcll(mask & ((1ull << lane) - 1ull));
-  int base = 0;
-  if (lane == 0 && mask != 0) base = atomicAdd(count, __popcll(mask));
-  base = __shfl(base, 0);
-  if (active) list[base + rank] = (int32_t)p;
+  if (lane == 0) wave_total[wave] = __popcll(mask);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int w = 0; w < 16; ++w) {
+      const int t = wave_total[w];
+      wave_total[w] = tot;   // exclusive prefix
+      tot += t;
+    }
+    block_base = tot ? atomicAdd(count, tot) : 0;
+  }
+  __syncthreads();
+  if (active) list[block_base + wave_total[wave] + rank] = (int32_t)p;
 }
 
 template <typename R, typename M>

@@ -46,9 +46,10 @@ def read_counters(path):
 
 
 def main():
-    tag = sys.argv[1]
-    dtype = sys.argv[2] if len(sys.argv) > 2 else "f32"
-    batch = int(sys.argv[3]) if len(sys.argv) > 3 else 262144
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    tag = args[0]
+    dtype = args[1] if len(args) > 1 else "f32"
+    batch = int(args[2]) if len(args) > 2 else 262144
     N = 40
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     out_dir = os.path.join(ROOT, "profiles")
@@ -110,10 +111,11 @@ def main():
             }
     with open(os.path.join(out_dir, tag + "_pmc_summary.json"), "w") as fh:
         json.dump(summary, fh, indent=1, sort_keys=True)
-    tname = "traffic_latest.json" if dtype == "f32" else "traffic_latest_%s.json" % dtype
-    with open(os.path.join(out_dir, tname), "w") as fh:
-        json.dump({"tag": tag, "dtype": dtype, "batch": batch, "per_launch_bytes": traffic,
-                   "source": "profiles/%s_pmc_summary.json" % tag}, fh, indent=1, sort_keys=True)
+    if traffic and "--no-traffic" not in sys.argv:   # the headline workload only: bench.py reads this file
+        tname = "traffic_latest.json" if dtype == "f32" else "traffic_latest_%s.json" % dtype
+        with open(os.path.join(out_dir, tname), "w") as fh:
+            json.dump({"tag": tag, "dtype": dtype, "batch": batch, "per_launch_bytes": traffic,
+                       "source": "profiles/%s_pmc_summary.json" % tag}, fh, indent=1, sort_keys=True)
     print(json.dumps(summary, indent=1, sort_keys=True))
 
 
