@@ -300,3 +300,51 @@ def test_batch_grows_between_steps(pkg, orc, pipeline):
     assert opt.previous_solution_batch() == 100
     opt.reset()
     assert opt.previous_solution_batch() == 0 and not opt.has_previous_solution()
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference's own integration tests (optimization/integration_test.cc:82-175) on the GPU path
+# ------------------------------------------------------------------------------------------------
+def _rk4_chain(pkg, params, x, steps, dt, dtype, fext_of_step=None):
+    """`steps` Jacobian-free RK4 steps (cpmpc_rk4_batch) of a [4, B] state tensor, u = 0."""
+    u = torch.zeros(x.shape[1], dtype=dtype, device=DEV)
+    for i in range(steps):
+        x = pkg.rk4_batch(params, x, u, dt, fext=fext_of_step(i) if fext_of_step else None, jacobians=False)
+    return x
+
+
+@pytest.mark.parametrize("dtype,tol_v,tol_w", [(torch.float64, 1e-6, 1e-4), (torch.float32, 1e-4, 1e-3)])
+def test_friction_dissipation_like_reference(pkg, dtype, tol_v, tol_w):
+    """TestFrictionDissipation (integration_test.cc:82-103): 20 000 steps from a level pole with mu_b = 0.5, no
+    control: the velocities die out (reference tolerances 1e-6 / 1e-4 in fp64; fp32 reported at 1e-4 / 1e-3)."""
+    p = [1.0, 0.5, 0.4, 9.81, 0.5, 0.1, 0.0, 0.0, 0.0]
+    x = _rk4_chain(pkg, p, T(np.zeros((4, 1)), dtype), 20000, 0.01, dtype)
+    x = N_(x)[:, 0]
+    assert abs(x[2]) < tol_v and abs(x[3]) < tol_w, x
+
+
+@pytest.mark.parametrize("dtype,tol_v,tol_w", [(torch.float64, 1e-6, 3e-5), (torch.float32, 1e-4, 1e-3)])
+def test_drag_dissipation_like_reference(pkg, dtype, tol_v, tol_w):
+    """TestDragDissipation (integration_test.cc:105-125): 10 000 steps from theta = -pi with c_d = 5."""
+    p = [0.8, 0.1, 0.4, 9.81, 0.01, 0.1, 5.0, 0.0, 0.0]
+    x0 = np.array([[0.0], [-np.pi], [0.0], [0.0]])
+    x = N_(_rk4_chain(pkg, p, T(x0, dtype), 10000, 0.01, dtype))[:, 0]
+    assert abs(x[2]) < tol_v and abs(x[3]) < tol_w, x
+
+
+def test_external_force_symmetry_like_reference(pkg):
+    """TestExternalForceSymmetry (integration_test.cc:127-175): +-5 N on the base for the first 500 of 3 000 steps of
+    1 ms from the hanging pole: mirror-symmetric final states to 1e-12 (both signs in one batch of two)."""
+    p = [1.0, 0.1, 0.25, 9.81, 0.1, 0.1, 0.0, 0.0, 0.0]
+    finals = []
+    for sign in (+1.0, -1.0):
+        x0 = np.array([[0.0], [-np.pi / 2], [0.0], [0.0]])
+        x = _rk4_chain(pkg, p, T(x0), 3000, 0.001, torch.float64,
+                       fext_of_step=lambda i, s=sign: [s * 5.0, 0.0, 0.0, 0.0] if i < 500 else None)
+        finals.append(N_(x)[:, 0])
+    left, right = finals
+    assert left[0] > 0 and right[0] < 0
+    assert abs(left[0] + right[0]) < 1e-12
+    assert abs(left[2] + right[2]) < 1e-12
+    assert abs((-np.pi / 2 - left[1]) - (right[1] + np.pi / 2)) < 1e-12
+    assert abs(left[3] + right[3]) < 1e-12
