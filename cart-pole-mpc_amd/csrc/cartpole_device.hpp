@@ -103,6 +103,24 @@ struct Math<float> {
 #ifndef CPMPC_F64_LIBM
 #define CPMPC_F64_LIBM 0
 #endif
+// Horner step p*z + C with the coefficient C read straight from a scalar register pair (VOP3 v_fma_f64 takes one
+// SGPR source).  Left to itself hipcc 7.2 keeps the ~24 fp64 polynomial coefficients of sincos/tanh in VGPRs across
+// the RK4 loops and, the kernel being at its register limit, re-assembles each one into an aligned VGPR pair
+// (v_mov_b64 + v_mov_b32) in front of a two-address v_fmac_f64: about 30 of the ~160 vector instructions of a stage
+// were such copies.  Materialising a coefficient in SGPRs is scalar-unit work that issues beside the vector stream.
+#ifndef CPMPC_F64_SGPR_COEF
+#define CPMPC_F64_SGPR_COEF 1
+#endif
+__device__ __forceinline__ double horner(double p, double z, double c) {
+#if CPMPC_F64_SGPR_COEF
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(z), "s"(c));
+  return r;
+#else
+  return ::fma(p, z, c);
+#endif
+}
+
 template <>
 struct Math<double> {
 #if CPMPC_F64_LIBM
@@ -117,17 +135,17 @@ struct Math<double> {
     const double z = r * r;
     // sin(r) = r + r z S(z)
     double sp = ::fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-    sp = ::fma(sp, z, 2.75573137070700676789e-06);
-    sp = ::fma(sp, z, -1.98412698298579493134e-04);
-    sp = ::fma(sp, z, 8.33333333332248946124e-03);
-    sp = ::fma(sp, z, -1.66666666666666324348e-01);
+    sp = horner(sp, z, 2.75573137070700676789e-06);
+    sp = horner(sp, z, -1.98412698298579493134e-04);
+    sp = horner(sp, z, 8.33333333332248946124e-03);
+    sp = horner(sp, z, -1.66666666666666324348e-01);
     const double sr = ::fma(r * z, sp, r);
     // cos(r) = w + ((1 - w) - z/2 + z z C(z)),  w = 1 - z/2
     double cp = ::fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-    cp = ::fma(cp, z, -2.75573143513906633035e-07);
-    cp = ::fma(cp, z, 2.48015872894767294178e-05);
-    cp = ::fma(cp, z, -1.38888888888741095749e-03);
-    cp = ::fma(cp, z, 4.16666666666666019037e-02);
+    cp = horner(cp, z, -2.75573143513906633035e-07);
+    cp = horner(cp, z, 2.48015872894767294178e-05);
+    cp = horner(cp, z, -1.38888888888741095749e-03);
+    cp = horner(cp, z, 4.16666666666666019037e-02);
     const double hz = 0.5 * z;
     const double w = 1.0 - hz;
     const double cr = w + (((1.0 - w) - hz) + z * z * cp);
@@ -152,17 +170,17 @@ struct Math<double> {
     r = ::fma(-nf, 1.90821492927058770002e-10, r);
     // expm1(r) = r + r^2 (1/2! + r (1/3! + ... + r / 13!)),  |r| <= ln2 / 2
     double p = 1.6059043836821613e-10;                       // 1/13!
-    p = ::fma(p, r, 2.08767569878680989792e-09);             // 1/12!
-    p = ::fma(p, r, 2.50521083854417187751e-08);             // 1/11!
-    p = ::fma(p, r, 2.75573192239858906526e-07);             // 1/10!
-    p = ::fma(p, r, 2.75573192239858906526e-06);             // 1/9!
-    p = ::fma(p, r, 2.48015873015873015873e-05);             // 1/8!
-    p = ::fma(p, r, 1.98412698412698412698e-04);             // 1/7!
-    p = ::fma(p, r, 1.38888888888888888889e-03);             // 1/6!
-    p = ::fma(p, r, 8.33333333333333333333e-03);             // 1/5!
-    p = ::fma(p, r, 4.16666666666666666667e-02);             // 1/4!
-    p = ::fma(p, r, 1.66666666666666666667e-01);             // 1/3!
-    p = ::fma(p, r, 0.5);                                    // 1/2!
+    p = horner(p, r, 2.08767569878680989792e-09);            // 1/12!
+    p = horner(p, r, 2.50521083854417187751e-08);            // 1/11!
+    p = horner(p, r, 2.75573192239858906526e-07);            // 1/10!
+    p = horner(p, r, 2.75573192239858906526e-06);            // 1/9!
+    p = horner(p, r, 2.48015873015873015873e-05);            // 1/8!
+    p = horner(p, r, 1.98412698412698412698e-04);            // 1/7!
+    p = horner(p, r, 1.38888888888888888889e-03);            // 1/6!
+    p = horner(p, r, 8.33333333333333333333e-03);            // 1/5!
+    p = horner(p, r, 4.16666666666666666667e-02);            // 1/4!
+    p = horner(p, r, 1.66666666666666666667e-01);            // 1/3!
+    p = horner(p, r, 0.5);                                   // 1/2!
     p = ::fma(r * r, p, r);
     const double two_n = ::ldexp(1.0, (int)nf);              // n in [-116, 0]
     const double t = ::fma(two_n, p, two_n - 1.0);           // expm1(y) in (-1, 0]
