@@ -38,6 +38,16 @@ from sympy.printing.c import C99CodePrinter
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def write_if_changed(path, text):
+    """Leave an up-to-date file alone (its mtime is a build dependency of the libraries)."""
+    if os.path.exists(path):
+        with open(path) as fh:
+            if fh.read() == text:
+                return
+    with open(path, "w") as fh:
+        fh.write(text)
+
+
 def derive_double():
     bx, th1, th2, v, w1, w2, u = sp.symbols("b_x th_1 th_2 b_x_dot th_1_dot th_2_dot u", real=True)
     m_b, m_1, m_2, l_1, l_2, g = sp.symbols("m_b m_1 m_2 l_1 l_2 g", real=True)
@@ -391,10 +401,8 @@ def write_single(model):
         if lang == "hip":
             lines.append("}  // namespace cpmpc")
         files[lang] = "\n".join(lines) + "\n"
-    with open(os.path.join(ROOT, "oracle", "single_pendulum_gen.inc"), "w") as fh:
-        fh.write(files["c"])
-    with open(os.path.join(ROOT, "cart-pole-mpc_amd", "csrc", "single_pendulum_gen.hpp"), "w") as fh:
-        fh.write(files["hip"])
+    write_if_changed(os.path.join(ROOT, "oracle", "single_pendulum_gen.inc"), files["c"])
+    write_if_changed(os.path.join(ROOT, "cart-pole-mpc_amd", "csrc", "single_pendulum_gen.hpp"), files["hip"])
     return files
 
 
@@ -404,11 +412,9 @@ def main():
               "// M(q) q'' = F(q, q', u): M[9] row-major, F[3], dFdx[3x6] row-major (x = [q, q']), dM1 = dM/dth_1, dM2 = dM/dth_2.",
               "// p = {m_b, m_1, m_2, l_1, l_2, g}; x = {b_x, th_1, th_2, b_x', th_1', th_2'}."]
     c_code = emit(model, "double", banner)
-    with open(os.path.join(ROOT, "oracle", "double_pendulum_gen.inc"), "w") as fh:
-        fh.write(c_code)
+    write_if_changed(os.path.join(ROOT, "oracle", "double_pendulum_gen.inc"), c_code)
     hip = emit(model, "R", banner + ["#pragma once", "namespace cpmpc {"]) + "}  // namespace cpmpc\n"
-    with open(os.path.join(ROOT, "cart-pole-mpc_amd", "csrc", "double_pendulum_gen.hpp"), "w") as fh:
-        fh.write(hip)
+    write_if_changed(os.path.join(ROOT, "cart-pole-mpc_amd", "csrc", "double_pendulum_gen.hpp"), hip)
     single = derive_single()
     files = write_single(single)
     print("single pendulum: a0 =", sp.simplify(single["acc"][0]))
