@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--pipeline", choices=["auto", "split", "fused"], default="auto")
     a = ap.parse_args()
     dt = torch.float32 if a.dtype == "f32" else torch.float64
     rng = np.random.default_rng(7)
@@ -38,6 +39,7 @@ def main():
         p = pkg.default_params(max_iterations=5, relative_exit_tol=0.0, absolute_first_derivative_tol=0.0,
                                u_guess_sinusoid_amplitude=0.0)
         opt = pkg.BatchOptimization(p, max_batch=B, dtype=dt, device=0, model="double")
+        opt.set_pipeline(a.pipeline)
         xt = torch.tensor(x0, dtype=dt, device="cuda:0")
 
         def step():
@@ -50,6 +52,7 @@ def main():
         sim = pkg.BatchSimulator(B, dtype=dt, device=0)
         sim.set_state(torch.tensor(xs, dtype=dt, device="cuda:0"))
         opt = pkg.BatchOptimization(pkg.default_params(), max_batch=B, dtype=dt, device=0)
+        opt.set_pipeline(a.pipeline)
 
         def step():
             o = opt.step(sim.get_state(), DYN_UI, 0.0, want_predicted=False, want_stats=True, out=out)
