@@ -57,9 +57,47 @@ SEED = 1000
 # ------------------------------------------------------------------------------------------------------------------
 # launcher: `python bench.py --gpus N` with no WORLD_SIZE starts the N ranks (nothing here touches the GPU)
 # ------------------------------------------------------------------------------------------------------------------
+def _env_device_list():
+    """Devices a *_VISIBLE_DEVICES variable leaves visible, or None when none is set."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return [t for t in v.split(",") if t.strip() != ""]
+    return None
+
+
+def kfd_gpu_nodes(root="/sys/class/kfd/kfd/topology/nodes"):
+    """GPU nodes of the KFD topology (a node with simd_count > 0 is a GPU, the others are CPUs): read from sysfs,
+    so counting them loads no runtime and creates no context."""
+    n = 0
+    try:
+        for node in sorted(os.listdir(root)):
+            try:
+                with open(os.path.join(root, node, "properties")) as fh:
+                    props = dict(ln.split()[:2] for ln in fh if len(ln.split()) >= 2)
+                if int(props.get("simd_count", "0")) > 0:
+                    n += 1
+            except (OSError, ValueError):
+                continue
+    except OSError:
+        return None
+    return n
+
+
 def visible_gpus():
-    import torch
-    return torch.cuda.device_count()   # counts devices without initialising the runtime on this image
+    """Number of GPUs the ranks will see, found WITHOUT touching the HIP runtime in this (launcher) process: the
+    KFD topology in sysfs, narrowed by a *_VISIBLE_DEVICES list; if sysfs is not there, a throw-away child process asks
+    the runtime (the launcher itself never does)."""
+    n = kfd_gpu_nodes()
+    env = _env_device_list()
+    if n is not None and n > 0:
+        return min(n, len(env)) if env is not None else n
+    try:
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                           capture_output=True, text=True, timeout=300)
+        return int(r.stdout.strip().splitlines()[-1])
+    except Exception:  # noqa: BLE001
+        return 0
 
 
 def rank_environments(n, n_devices, share, port):
@@ -88,28 +126,56 @@ def free_port():
 
 def launch_ranks(n, argv, n_devices=None, script=None, timeout=None):
     """Start n fresh rank processes (never a re-exec of a process that has touched the GPU), wait for them and return
-    (exit code, rank 0's stdout).  Rank 0's stdout is captured, the other ranks write to stderr."""
+    (exit code, rank 0's stdout).  Rank 0's stdout is captured (read on a thread, so a full pipe never blocks it), the
+    other ranks write to stderr.  All ranks are polled together: the first one to exit non-zero ends the run at once --
+    the others (which would otherwise sit in a collective until its timeout) are killed and that exit code is returned.
+    `timeout` (default CPMPC_BENCH_TIMEOUT or 3600 s) bounds the whole run the same way.  Never restarts anything."""
+    import threading
     share = os.environ.get("CPMPC_BENCH_SHARE_DEVICE", "0") == "1"
     if n_devices is None:
         n_devices = visible_gpus()
+    if timeout is None:
+        timeout = float(os.environ.get("CPMPC_BENCH_TIMEOUT", "3600"))
     envs = rank_environments(n, n_devices, share, free_port())
     cmd = [sys.executable, script or os.path.abspath(__file__)] + list(argv)
     procs = []
-    for r, e in enumerate(envs):
-        procs.append(subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr,
-                                      text=True))
-    out0 = ""
+    chunks = []
+    reader = None
     rc = 0
     try:
-        out0, _ = procs[0].communicate(timeout=timeout)
-        for p in procs:
-            p.wait(timeout=timeout)
-            rc = rc or p.returncode
+        for r, e in enumerate(envs):
+            procs.append(subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if r == 0 else sys.stderr,
+                                          stderr=sys.stderr, text=True))
+        reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+        reader.start()
+        deadline = time.monotonic() + timeout
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad:
+                rc = bad[0]
+                sys.stderr.write("bench.py launcher: rank %d exited with code %d; stopping the other ranks\n"
+                                 % (codes.index(bad[0]), bad[0]))
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.monotonic() > deadline:
+                rc = 124
+                sys.stderr.write("bench.py launcher: no result after %.0f s; stopping the ranks\n" % timeout)
+                break
+            time.sleep(0.05)
     finally:
         for p in procs:   # exactly the processes started here
             if p.poll() is None:
                 p.kill()
-    return rc, out0
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                pass
+        if reader is not None:
+            reader.join(timeout=30)
+    return rc, "".join(c for c in chunks if c)
 
 
 def last_json_line(text):
@@ -193,7 +259,8 @@ def cpu_baseline(x0_np, over, seconds_target=20.0):
 
 def timed_region(torch, dist, sharding, opt, x0, outs, gather, steps, warmup, dev, local_rank, distributed):
     """W untimed steps, then exactly K steps bracketed by barrier + synchronize on both sides.  Returns
-    (max-over-ranks seconds, per-kernel HIP-event profile of the timed steps, outputs of the last step, its slot)."""
+    (max-over-ranks seconds, this rank's own seconds up to the end of its last step and gather -- before the closing
+    barrier --, per-kernel HIP-event profile of the timed steps, outputs of the last step, its slot)."""
     state = {"n": 0, "slot": 0}
 
     def one_step():
@@ -225,12 +292,16 @@ def timed_region(torch, dist, sharding, opt, x0, outs, gather, steps, warmup, de
     t0 = time.perf_counter()
     for _ in range(steps):
         out = one_step()
+    if gather is not None:
+        gather.finish()
+    torch.cuda.synchronize()
+    own = time.perf_counter() - t0      # this rank's work alone (diagnostic; the reported time is the one below)
     fence()
     elapsed = time.perf_counter() - t0
     elapsed = sharding.max_over_ranks(elapsed, dev if dist.is_initialized() and dist.get_backend() == "nccl" else "cpu")
     prof = opt.profile_read()
     opt.profile_enable(False)
-    return elapsed, prof, out, state["slot"]
+    return elapsed, own, prof, out, state["slot"]
 
 
 def roofline_of(prof, dtype, B, iters, steps, rate_per_gpu):
@@ -395,6 +466,14 @@ def run_rank(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # --as-rank R --of W: this ONE process solves exactly what rank R of a W-GPU run would solve (its contiguous block
+    # of the one seeded W x batch global batch) with no process group: configs[3]'s per-GPU work on the GPU at hand
+    as_rank = args.as_rank is not None
+    if as_rank:
+        if args.of is None or not 0 <= args.as_rank < args.of:
+            raise SystemExit("--as-rank R needs --of W with 0 <= R < W")
+        if world != 1 or args.gpus != 1:
+            raise SystemExit("--as-rank runs in one process on one GPU (no --gpus, no torch.distributed.run)")
     if world != args.gpus:
         raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (python bench.py --gpus N starts "
                          "them itself; torch.distributed.run must use --nproc-per-node N)" % (args.gpus, world))
@@ -430,8 +509,9 @@ def run_rank(args):
     params = pkg.default_params(**over)
     N = int(params.window_length)
 
-    total = world * B
-    lo, hi = sharding.shard_range(total, rank, world)    # my contiguous block of the one global batch
+    shard_world, shard_rank = (args.of, args.as_rank) if as_rank else (world, rank)
+    total = shard_world * B
+    lo, hi = sharding.shard_range(total, shard_rank, shard_world)    # my contiguous block of the one global batch
     assert hi - lo == B
     x0_np = synth_states(SEED, total, lo, hi)
     x0 = torch.tensor(x0_np, dtype=tdt, device=dev)
@@ -443,8 +523,8 @@ def run_rank(args):
         gather = sharding.ResultGather(N, B, tdt, dev, dst=0, depth=2, force=force_dist,
                                        via_host=(backend == "gloo"))
 
-    elapsed, prof, out, slot = timed_region(torch, dist, sharding, opt, x0, outs, gather, args.steps, args.warmup, dev,
-                                            local_rank, distributed)
+    elapsed, own_s, prof, out, slot = timed_region(torch, dist, sharding, opt, x0, outs, gather, args.steps, args.warmup,
+                                                   dev, local_rank, distributed)
 
     # the gather on its own: the same [N, B] block from every rank to rank 0, nothing else in flight
     gather_ms = None
@@ -460,31 +540,53 @@ def run_rank(args):
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - t0) / reps * 1e3
 
+    # per-rank diagnostics (one small all-gather, outside the timed region): each rank's own time per step, the
+    # average launch time of its SQP kernel, and its view of the stand-alone gather
+    per_rank = None
+    if distributed:
+        fused = prof.get("fused_sqp_kernel", (0.0, 0))
+        per_rank = sharding.all_ranks([own_s / args.steps * 1e3, fused[0] / max(fused[1], 1),
+                                       gather_ms if gather_ms is not None else -1.0],
+                                      dev if dist.get_backend() == "nccl" else "cpu")
+
     if rank != 0:
         if dist.is_initialized():
             dist.barrier()
             dist.destroy_process_group()
         return
 
-    value = total * args.steps / elapsed
+    value = world * B * args.steps / elapsed    # problems all ranks of THIS run solved per second
     line = {
         "metric": "MPC re-plans/sec (whole node), N=40 horizon, 5 SQP iters, batch 256k",
         "value": value, "unit": "re-plans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "BASELINE configs[%d]: batch=%d per GPU (%d in total), N=40, state_spacing=10, %s, cold start, "
+        "config": {"workload": "BASELINE configs[%d]%s: batch=%d per GPU (%d in total), N=40, state_spacing=10, %s, cold start, "
                                "%d SQP iterations (exits disabled), u+predicted+status written%s"
-                               % (2 if world == 1 else 3, B, total, args.dtype, args.iters,
+                               % (2 if shard_world == 1 else 3,
+                                  " -- the shard of rank %d of %d, solved alone on this GPU" % (shard_rank, shard_world)
+                                  if as_rank else "", B, total, args.dtype, args.iters,
                                   ", u gathered to rank 0 (%s)" % ("RCCL" if backend == "nccl" else "gloo") if gather else ""),
                    "batch_per_gpu": B, "global_batch": total, "horizon": N, "sqp_iterations": args.iters,
                    "pipeline": opt.pipeline(), "parallelism": "dp%d" % world},
         "roofline": roofline_of(prof, args.dtype, B, args.iters, args.steps, value / world),
     }
+    if as_rank:
+        line["as_rank"] = {"rank": shard_rank, "of": shard_world, "columns_of_global_batch": [lo, hi],
+                           "note": "value is this one GPU's rate on that shard; no process group, no gather"}
     if distributed:
+        own_ms = [r[0] for r in per_rank]
         line["distributed"] = {"world_size_seen": dist.get_world_size(), "backend": dist.get_backend(),
                                "spawned_by_bench": os.environ.get("CPMPC_BENCH_SPAWNED", "0") == "1",
                                "shard_of_rank0": [lo, hi], "gather_ms": gather_ms,
-                               "devices_visible": n_dev}
+                               "devices_visible": n_dev,
+                               "per_rank": {"ms_per_step_own": own_ms, "ms_per_step_own_min": min(own_ms),
+                                            "ms_per_step_own_max": max(own_ms),
+                                            "sqp_kernel_ms_per_launch": [r[1] for r in per_rank],
+                                            "gather_ms": [r[2] if r[2] >= 0 else None for r in per_rank],
+                                            "note": "own = W..K steps + gather on that rank up to its own synchronize, "
+                                                    "before the closing barrier; ms_per_step is the max over ranks "
+                                                    "including the barrier"}}
     # everything below is secondary: a failure in one leg is recorded, never raised (the primary line must print)
     try:
         st = out.status.cpu().numpy()
@@ -508,13 +610,27 @@ def run_rank(args):
 
     # ---- the parity dtype as a first-class record: same workload, same batch, fp64, timed the same way ----------
     u64 = st64 = None
+    if as_rank and args.parity_lanes > 0:
+        # sampled lanes of this shard against the CPU oracle on the same columns of the global batch (checker only)
+        try:
+            from oracle import oracle as orc
+            idx = np.unique(np.linspace(0, B - 1, args.parity_lanes).astype(np.int64))
+            u_cpu, _, st_cpu, _, _ = orc.step_batch_cold(orc.default_opt_params(**over), DYN_UI, 0.0, x0_np[:, idx])
+            u_g = out.u.double().cpu().numpy()[:, idx]
+            ps, _ = parity_stats(u_g, u_cpu, st[idx], st_cpu)
+            ps.update({"bar": 1e-5, "global_columns_first_last": [int(lo + idx[0]), int(lo + idx[-1])]})
+            line["as_rank"]["parity"] = ps
+        except Exception as exc:  # noqa: BLE001
+            line["as_rank"]["parity"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    if as_rank:   # the secondary legs belong to the headline run
+        args.no_fp64 = args.no_variants = args.no_cpu_baseline = True
     if world == 1 and args.dtype == "f32" and not args.no_fp64:
         try:
             opt64 = pkg.BatchOptimization(params, max_batch=B, dtype=torch.float64, device=local_rank)
             opt64.set_pipeline(args.pipeline)
             x64 = torch.tensor(x0_np, dtype=torch.float64, device=dev)
             outs64 = [pkg.BatchOutputs(), pkg.BatchOutputs()]
-            el64, prof64, o64, _ = timed_region(torch, dist, sharding, opt64, x64, outs64, None, args.steps, args.warmup,
+            el64, _, prof64, o64, _ = timed_region(torch, dist, sharding, opt64, x64, outs64, None, args.steps, args.warmup,
                                                 dev, local_rank, False)
             v64 = B * args.steps / el64
             line["fp64"] = {"value": v64, "unit": "re-plans/s", "dtype": "f64", "steps": args.steps, "warmup": args.warmup,
@@ -586,6 +702,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-fp64", action="store_true", help="skip the fp64 record")
     ap.add_argument("--no-variants", action="store_true", help="skip the secondary measurements (SURVEY 8d)")
     ap.add_argument("--pipeline", choices=["auto", "split", "fused"], default="auto")
+    ap.add_argument("--as-rank", type=int, default=None, help="with --of W: solve rank R's shard of the W-GPU global "
+                    "batch alone on this GPU (no process group)")
+    ap.add_argument("--of", type=int, default=None)
+    ap.add_argument("--parity-lanes", type=int, default=0, help="with --as-rank: compare this many sampled lanes of the "
+                    "shard with the CPU oracle (fp64 bar 1e-5)")
     return ap.parse_args(argv)
 
 

@@ -56,12 +56,19 @@ def build_variant(name, flags, force=False, verbose=False):
     if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in _deps()):
         return out
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC"] + \
-        list(flags) + ["-o", out + ".tmp"] + SOURCES
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
-    os.replace(out + ".tmp", out)
+    import fcntl
+    with open(os.path.join(os.path.dirname(out), ".build.lock"), "w") as lock:  # one builder at a time, as build_lib
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in _deps()):
+            return out
+        tmp = out + ".tmp.%d" % os.getpid()
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC"] + \
+            list(flags) + ["-o", tmp] + SOURCES
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd, stdout=subprocess.DEVNULL if not verbose else None,
+                              stderr=subprocess.DEVNULL if not verbose else None)
+        os.replace(tmp, out)
     return out
 
 
@@ -74,7 +81,12 @@ def _compile(verbose):
            "-o", tmp] + SOURCES
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+    # hipcc's warnings (hundreds of "loop not unrolled" remarks for the run-time-spacing kernels) are shown only when asked
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0 or verbose:
+        sys.stderr.write(r.stdout)
+    if r.returncode != 0:
+        raise subprocess.CalledProcessError(r.returncode, cmd)
     os.replace(tmp, LIB)  # atomic: a concurrent loader never sees a half-written library
     return LIB
 
@@ -82,6 +94,7 @@ def _compile(verbose):
 HOST = os.path.join(HERE, "host")
 HOST_LIB = os.path.join(LIB_DIR, "libpendulum_host.so")
 HOST_SMOKE = os.path.join(LIB_DIR, "host_smoke")
+SHARDED_SMOKE = os.path.join(LIB_DIR, "sharded_smoke")
 
 
 def _pymod_path():
@@ -95,8 +108,9 @@ def build_host(force=False, verbose=False):
     import sysconfig
 
     build_lib()
-    srcs = [os.path.join(HOST, f) for f in ("optimization.cc", "simulator.cc", "json.cc")]
-    hdrs = [os.path.join(HOST, f) for f in ("optimization.hpp", "simulator.hpp", "structs.hpp", "json.hpp")]
+    srcs = [os.path.join(HOST, f) for f in ("optimization.cc", "sharded_optimization.cc", "simulator.cc", "json.cc")]
+    hdrs = [os.path.join(HOST, f) for f in ("optimization.hpp", "sharded_optimization.hpp", "simulator.hpp", "structs.hpp",
+                                            "json.hpp")]
     cxx = os.environ.get("CXX", "g++")
     common = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-Wextra"]
     link = ["-L" + LIB_DIR, "-lcpmpc", "-Wl,-rpath,$ORIGIN"]
@@ -112,10 +126,13 @@ def build_host(force=False, verbose=False):
 
     if stale(HOST_LIB, srcs + hdrs):
         run([cxx] + common + ["-shared", "-o", HOST_LIB] + srcs + link)
-    smoke_src = os.path.join(HERE, "..", "tests", "host", "closed_loop_like_reference.cc")  # test infrastructure
-    if stale(HOST_SMOKE, [smoke_src, HOST_LIB] + hdrs):
-        run([cxx] + common + ["-I" + HOST, "-o", HOST_SMOKE, smoke_src, "-L" + LIB_DIR, "-lpendulum_host", "-lcpmpc",
-                              "-Wl,-rpath,$ORIGIN"])
+    # test infrastructure: C++ callers of the facade (closed loop through Optimization + Simulator; several shards
+    # against one handle)
+    for target, name in ((HOST_SMOKE, "facade_closed_loop.cc"), (SHARDED_SMOKE, "sharded_smoke.cc")):
+        src = os.path.join(HERE, "..", "tests", "host", name)
+        if stale(target, [src, HOST_LIB] + hdrs):
+            run([cxx] + common + ["-I" + HOST, "-o", target, src, "-L" + LIB_DIR, "-lpendulum_host", "-lcpmpc",
+                                  "-Wl,-rpath,$ORIGIN"])
     try:
         import pybind11
     except ImportError:

@@ -38,6 +38,9 @@ SYMBOLS = [
     "cpmpc_model", "cpmpc_dynamics_batch_model", "cpmpc_rk4_batch_model", "cpmpc_sim_step_batch_model",
     "cpmpc_set_pipeline", "cpmpc_get_pipeline", "cpmpc_set_compaction",
     "cpmpc_profile_enable", "cpmpc_profile_reset", "cpmpc_profile_read", "cpmpc_kernel_name",
+    "cpmpc_sharded_create", "cpmpc_sharded_destroy", "cpmpc_sharded_num_shards", "cpmpc_sharded_device",
+    "cpmpc_sharded_handle", "cpmpc_sharded_range", "cpmpc_sharded_reset", "cpmpc_sharded_step_batch_host",
+    "cpmpc_sharded_step_batch",
 ]
 
 
@@ -193,6 +196,18 @@ def load():
     L.cpmpc_profile_read.argtypes = [vp, i32, _dp, C.POINTER(C.c_int64)]
     L.cpmpc_kernel_name.argtypes = [i32]
     L.cpmpc_kernel_name.restype = C.c_char_p
+    L.cpmpc_sharded_create.argtypes = [C.POINTER(Params), C.POINTER(SolverOpts), i32, i64, C.POINTER(C.c_int), i32,
+                                       C.POINTER(vp)]
+    L.cpmpc_sharded_destroy.argtypes = [vp]
+    L.cpmpc_sharded_destroy.restype = None
+    L.cpmpc_sharded_num_shards.argtypes = [vp]
+    L.cpmpc_sharded_device.argtypes = [vp, i32]
+    L.cpmpc_sharded_handle.argtypes = [vp, i32]
+    L.cpmpc_sharded_handle.restype = vp
+    L.cpmpc_sharded_range.argtypes = [vp, i32, i64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.cpmpc_sharded_reset.argtypes = [vp]
+    L.cpmpc_sharded_step_batch_host.argtypes = [vp, i64, _dp, _dp, dbl, C.POINTER(StepHostOutputs)]
+    L.cpmpc_sharded_step_batch.argtypes = [vp, i64, vp, _dp, dbl, C.POINTER(StepOutputs), vp]
     _lib = L
     return L
 

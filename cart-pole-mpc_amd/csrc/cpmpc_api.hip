@@ -773,6 +773,9 @@ extern "C" int cpmpc_get_solution(cpmpc_solver* s, int64_t B, void* z_out, void*
                  hipLaunchKernelGGL((unpack_z_kernel<R, M::NX>), grid_for(B), dim3(64), 0, (hipStream_t)stream, B,
                                     s->cap, s->S, s->N, (const XV<R, M::NX>*)s->zx, (const R*)s->zu, (R*)z_out));
   HIP_TRY(hipGetLastError());
+  // this read of zx/zu on the caller's stream must finish before a later host-pointer call (on the handle's own
+  // stream) overwrites them
+  track_caller_stream(s, (hipStream_t)stream);
   return CPMPC_OK;
 }
 
@@ -811,31 +814,56 @@ static int ensure_stage(cpmpc_solver* s, size_t bytes) {
   return CPMPC_OK;
 }
 
+// A host-pointer step in two halves, so that several handles (the shards of cpmpc_sharded_*) can have their copies and
+// kernels in flight together: `begin` converts and uploads the inputs and queues the kernels and the copy back on the
+// handle's own stream; `end` waits for that stream and scatters the results into the caller's arrays.  The caller's
+// arrays are [field][ld] with this handle's B problems at columns [col0, col0 + B): ld = B, col0 = 0 for a plain call.
+struct HostStepLayout {
+  size_t off_u = 0, off_cost = 0, off_eq = 0, off_status = 0, off_iters = 0, off_sol = 0, off_pred = 0;  // bytes
+};
+
 template <typename R, typename M>
-static int step_host_impl(cpmpc_solver* s, int64_t B, const double* x0_host, const double* dyn_shared_host,
-                          double set_point, const cpmpc_step_host_outputs& ho) {
+static HostStepLayout host_step_layout(const cpmpc_solver* s, int64_t B) {
   // staging layout, identical on the device and in the pinned mirror:
   //   [x0 | u | cost | eq | status | iters | solution | predicted]      (the optional tails last: one copy back)
   const size_t nB = (size_t)B;
-  const size_t n_x0 = (size_t)M::NX * nB, n_u = (size_t)s->N * nB, n_pred = (size_t)M::NX * (size_t)s->N * nB;
-  const size_t n_sol = (size_t)s->dim * nB;
-  const size_t bytes = (n_x0 + n_u + 2 * nB + n_sol + n_pred) * sizeof(R) + 2 * nB * sizeof(int32_t) + 64;
+  HostStepLayout L;
+  L.off_u = (size_t)M::NX * nB * sizeof(R);
+  L.off_cost = L.off_u + (size_t)s->N * nB * sizeof(R);
+  L.off_eq = L.off_cost + nB * sizeof(R);
+  L.off_status = L.off_eq + nB * sizeof(R);
+  L.off_iters = L.off_status + nB * sizeof(int32_t);
+  L.off_sol = (L.off_iters + nB * sizeof(int32_t) + 7) & ~(size_t)7;  // the real-typed tail starts 8-byte aligned
+  L.off_pred = L.off_sol + (size_t)s->dim * nB * sizeof(R);
+  return L;
+}
+
+template <typename R, typename M>
+static int step_host_begin(cpmpc_solver* s, int64_t B, const double* x0_host, int64_t ld, int64_t col0,
+                           const double* dyn_shared_host, double set_point, bool want_pred, bool want_sol) {
+  const size_t nB = (size_t)B;
+  const size_t n_pred = (size_t)M::NX * (size_t)s->N * nB;
+  const HostStepLayout L = host_step_layout<R, M>(s, B);
+  const size_t bytes = L.off_pred + n_pred * sizeof(R) + 64;
   int rc = ensure_stage(s, bytes);
   if (rc) return rc;
-  R* d_x0 = (R*)s->stage;
-  R* d_u = d_x0 + n_x0;
-  R* d_cost = d_u + n_u;
-  R* d_eq = d_cost + nB;
-  int32_t* d_status = (int32_t*)(d_eq + nB);
-  int32_t* d_iters = d_status + nB;
-  // the real-typed tail starts 8-byte aligned after the 2 nB int32
-  R* d_sol = (R*)(((uintptr_t)(d_iters + nB) + 7) & ~(uintptr_t)7);
-  R* d_pred = d_sol + n_sol;
+  char* d_base = (char*)s->stage;
+  R* d_x0 = (R*)d_base;
   R* h_x0 = (R*)s->pin;
   const hipStream_t st = s->hstream;
-
-  for (size_t i = 0; i < n_x0; ++i) h_x0[i] = (R)x0_host[i];
-  HIP_TRY(hipMemcpyAsync(d_x0, h_x0, n_x0 * sizeof(R), hipMemcpyHostToDevice, st));
+  // from here on work is in flight on `st` that reads the pinned mirror and writes the staging buffer: every early
+  // return drains the stream first, so that the next call never reuses them under a running copy
+  auto bail = [&](int code) {
+    (void)hipStreamSynchronize(st);
+    return code;
+  };
+  for (int t = 0; t < M::NX; ++t) {
+    const double* src = x0_host + (size_t)t * (size_t)ld + (size_t)col0;
+    R* dst = h_x0 + (size_t)t * nB;
+    for (size_t i = 0; i < nB; ++i) dst[i] = (R)src[i];
+  }
+  hipError_t e = hipMemcpyAsync(d_x0, h_x0, L.off_u, hipMemcpyHostToDevice, st);
+  if (e != hipSuccess) return bail(fail(CPMPC_ERR_HIP, "hipMemcpyAsync (inputs) failed: %s", hipGetErrorString(e)));
 
   cpmpc_step_inputs in;
   memset(&in, 0, sizeof in);
@@ -844,38 +872,56 @@ static int step_host_impl(cpmpc_solver* s, int64_t B, const double* x0_host, con
   in.set_point_shared = set_point;
   cpmpc_step_outputs out;
   memset(&out, 0, sizeof out);
-  out.u = d_u;
-  out.predicted = ho.predicted ? d_pred : nullptr;
-  out.status = d_status;
-  out.iterations = d_iters;
-  out.final_cost = d_cost;
-  out.final_eq_l1 = d_eq;
-  out.solution = ho.solution ? d_sol : nullptr;
+  out.u = d_base + L.off_u;
+  out.predicted = want_pred ? d_base + L.off_pred : nullptr;
+  out.status = (int32_t*)(d_base + L.off_status);
+  out.iterations = (int32_t*)(d_base + L.off_iters);
+  out.final_cost = d_base + L.off_cost;
+  out.final_eq_l1 = d_base + L.off_eq;
+  out.solution = want_sol ? d_base + L.off_sol : nullptr;
   rc = step_batch_impl<R, M>(s, B, &in, &out, st);
-  if (rc) return rc;
+  if (rc) return bail(rc);
   // one copy back, from u to the end of what was asked for
-  char* h_base = (char*)s->pin;
-  const char* d_base = (const char*)s->stage;
-  const char* d_end = ho.predicted ? (const char*)(d_pred + n_pred)
-                                   : (ho.solution ? (const char*)(d_sol + n_sol) : (const char*)(d_iters + nB));
-  const size_t off_u = (size_t)((const char*)d_u - d_base);
-  HIP_TRY(hipMemcpyAsync(h_base + off_u, d_u, (size_t)(d_end - (const char*)d_u), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-
-  auto fetch = [&](const R* dsrc, double* hdst, size_t n) {
-    if (!hdst) return;
-    const R* h = (const R*)(h_base + ((const char*)dsrc - d_base));
-    for (size_t i = 0; i < n; ++i) hdst[i] = (double)h[i];
-  };
-  fetch(d_u, ho.u, n_u);
-  fetch(d_cost, ho.final_cost, nB);
-  fetch(d_eq, ho.final_eq_l1, nB);
-  fetch(d_sol, ho.solution, n_sol);
-  fetch(d_pred, ho.predicted, n_pred);
-  const int32_t* h_status = (const int32_t*)(h_base + ((const char*)d_status - d_base));
-  if (ho.status) memcpy(ho.status, h_status, nB * sizeof(int32_t));
-  if (ho.iterations) memcpy(ho.iterations, h_status + nB, nB * sizeof(int32_t));
+  const size_t end = want_pred ? L.off_pred + n_pred * sizeof(R)
+                               : (want_sol ? L.off_pred : L.off_iters + nB * sizeof(int32_t));
+  e = hipMemcpyAsync((char*)s->pin + L.off_u, d_base + L.off_u, end - L.off_u, hipMemcpyDeviceToHost, st);
+  if (e != hipSuccess) return bail(fail(CPMPC_ERR_HIP, "hipMemcpyAsync (outputs) failed: %s", hipGetErrorString(e)));
   return CPMPC_OK;
+}
+
+template <typename R, typename M>
+static int step_host_end(cpmpc_solver* s, int64_t B, const cpmpc_step_host_outputs& ho, int64_t ld, int64_t col0) {
+  HIP_TRY(hipStreamSynchronize(s->hstream));
+  const size_t nB = (size_t)B;
+  const HostStepLayout L = host_step_layout<R, M>(s, B);
+  const char* h_base = (const char*)s->pin;
+  // rows of B scalars in the mirror -> rows of ld scalars in the caller's array, at column col0
+  auto fetch = [&](size_t off, double* hdst, size_t rows) {
+    if (!hdst) return;
+    const R* h = (const R*)(h_base + off);
+    for (size_t r = 0; r < rows; ++r) {
+      double* dst = hdst + r * (size_t)ld + (size_t)col0;
+      const R* src = h + r * nB;
+      for (size_t i = 0; i < nB; ++i) dst[i] = (double)src[i];
+    }
+  };
+  fetch(L.off_u, ho.u, (size_t)s->N);
+  fetch(L.off_cost, ho.final_cost, 1);
+  fetch(L.off_eq, ho.final_eq_l1, 1);
+  fetch(L.off_sol, ho.solution, (size_t)s->dim);
+  fetch(L.off_pred, ho.predicted, (size_t)M::NX * (size_t)s->N);
+  if (ho.status) memcpy(ho.status + col0, h_base + L.off_status, nB * sizeof(int32_t));
+  if (ho.iterations) memcpy(ho.iterations + col0, h_base + L.off_iters, nB * sizeof(int32_t));
+  return CPMPC_OK;
+}
+
+template <typename R, typename M>
+static int step_host_impl(cpmpc_solver* s, int64_t B, const double* x0_host, const double* dyn_shared_host,
+                          double set_point, const cpmpc_step_host_outputs& ho) {
+  const int rc = step_host_begin<R, M>(s, B, x0_host, B, 0, dyn_shared_host, set_point, ho.predicted != nullptr,
+                                       ho.solution != nullptr);
+  if (rc) return rc;
+  return step_host_end<R, M>(s, B, ho, B, 0);
 }
 
 extern "C" int cpmpc_step_batch_host_ex(cpmpc_solver* s, int64_t B, const double* x0_host,
@@ -915,7 +961,10 @@ extern "C" int cpmpc_set_previous_solution_host(cpmpc_solver* s, int64_t B, cons
   }
   HIP_TRY(hipMemcpyAsync(s->stage, s->pin, n * s->esize, hipMemcpyHostToDevice, s->hstream));
   rc = cpmpc_set_previous_solution(s, B, s->stage, s->hstream);
-  if (rc) return rc;
+  if (rc) {
+    (void)hipStreamSynchronize(s->hstream);  // the copy above still reads the pinned mirror
+    return rc;
+  }
   HIP_TRY(hipStreamSynchronize(s->hstream));
   return CPMPC_OK;
 }
@@ -929,13 +978,274 @@ extern "C" int cpmpc_get_solution_host(cpmpc_solver* s, int64_t B, double* z_hos
   if (rc) return rc;
   rc = cpmpc_get_solution(s, B, s->stage, s->hstream);
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(s->pin, s->stage, n * s->esize, hipMemcpyDeviceToHost, s->hstream));
-  HIP_TRY(hipStreamSynchronize(s->hstream));
+  {
+    const hipError_t e = hipMemcpyAsync(s->pin, s->stage, n * s->esize, hipMemcpyDeviceToHost, s->hstream);
+    const hipError_t e2 = hipStreamSynchronize(s->hstream);  // also on failure: the unpack kernel is in flight
+    if (e != hipSuccess) return fail(CPMPC_ERR_HIP, "hipMemcpyAsync failed: %s", hipGetErrorString(e));
+    if (e2 != hipSuccess) return fail(CPMPC_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e2));
+  }
   if (s->dtype == CPMPC_F32) {
     const float* h = (const float*)s->pin;
     for (size_t i = 0; i < n; ++i) z_host[i] = (double)h[i];
   } else {
     memcpy(z_host, s->pin, n * 8);
+  }
+  return CPMPC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// several GPUs from one process: one handle + stream per shard, contiguous split, concurrent shards
+// ------------------------------------------------------------------------------------------------
+struct Shard {
+  cpmpc_solver* h = nullptr;
+  int device = 0;
+  hipStream_t stream = nullptr;   // device-pointer steps of this shard run here
+  hipEvent_t ready = nullptr;     // root stream -> shard stream (inputs are there)
+  hipEvent_t done = nullptr;      // shard stream -> root stream (results have landed on the root device)
+  void* buf = nullptr;            // per-shard device staging: [x0 | u | predicted | cost | eq | status | iters]
+  size_t buf_bytes = 0;
+};
+
+struct cpmpc_sharded {
+  std::vector<Shard> shards;
+  int dtype = CPMPC_F64;
+  int N = 0, NX = 4;
+  size_t esize = 8;
+  int64_t cap = 0;
+};
+
+static void shard_range(int64_t total, int i, int n, int64_t* lo, int64_t* hi) {
+  const int64_t base = total / n, rem = total % n;
+  *lo = (int64_t)i * base + (i < rem ? i : rem);
+  *hi = *lo + base + (i < rem ? 1 : 0);
+}
+
+extern "C" void cpmpc_sharded_destroy(cpmpc_sharded* s) {
+  if (!s) return;
+  for (auto& sh : s->shards) {
+    DeviceGuard guard(sh.device);
+    if (sh.stream) (void)hipStreamSynchronize(sh.stream);
+    if (sh.h) cpmpc_destroy(sh.h);
+    if (sh.buf) (void)hipFree(sh.buf);
+    if (sh.ready) (void)hipEventDestroy(sh.ready);
+    if (sh.done) (void)hipEventDestroy(sh.done);
+    if (sh.stream) (void)hipStreamDestroy(sh.stream);
+  }
+  delete s;
+}
+
+extern "C" int cpmpc_sharded_create(const cpmpc_params* params, const cpmpc_solver_opts* opts, int dtype,
+                                    int64_t max_batch, const int* devices, int n_devices, cpmpc_sharded** out) {
+  if (!params || !out) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
+  *out = nullptr;
+  std::vector<int> devs;
+  if (devices == nullptr) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+      return fail(CPMPC_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU fallback");
+    for (int i = 0; i < n; ++i)
+      if (device_is_gfx950(i)) devs.push_back(i);
+    if (devs.empty()) return fail(CPMPC_ERR_NO_DEVICE, "no gfx950 device visible");
+  } else {
+    if (n_devices < 1 || n_devices > 64) return fail(CPMPC_ERR_INVALID_ARG, "n_devices must be in [1, 64]");
+    devs.assign(devices, devices + n_devices);
+  }
+  const int n = (int)devs.size();
+  if (max_batch < n) return fail(CPMPC_ERR_INVALID_ARG, "max_batch must be at least the number of shards");
+  cpmpc_sharded* s = new (std::nothrow) cpmpc_sharded();
+  if (!s) return fail(CPMPC_ERR_ALLOC, "out of host memory");
+  s->dtype = dtype;
+  s->esize = dtype == CPMPC_F32 ? 4 : 8;
+  s->cap = max_batch;
+  s->shards.resize(n);
+  for (int i = 0; i < n; ++i) {
+    Shard& sh = s->shards[i];
+    sh.device = devs[i];
+    int64_t lo, hi;
+    shard_range(max_batch, i, n, &lo, &hi);
+    int rc = cpmpc_create(params, opts, dtype, hi - lo + 1, sh.device, &sh.h);  // +1: a smaller B may shift a remainder here
+    if (rc == CPMPC_OK) {
+      DeviceGuard guard(sh.device);
+      if (hipStreamCreateWithFlags(&sh.stream, hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&sh.ready, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&sh.done, hipEventDisableTiming) != hipSuccess)
+        rc = fail(CPMPC_ERR_HIP, "stream / event creation failed on device %d", sh.device);
+    }
+    if (rc != CPMPC_OK) {
+      cpmpc_sharded_destroy(s);
+      return rc;
+    }
+  }
+  s->N = s->shards[0].h->N;
+  s->NX = s->shards[0].h->NX;
+  // peer access between the root device and every other shard's device (both directions); a pair that cannot be
+  // mapped still works, the copies then go through host memory
+  const int root = s->shards[0].device;
+  for (int i = 1; i < n; ++i) {
+    const int d = s->shards[i].device;
+    if (d == root) continue;
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, root, d) == hipSuccess && can) {
+      DeviceGuard guard(root);
+      (void)hipDeviceEnablePeerAccess(d, 0);
+    }
+    if (hipDeviceCanAccessPeer(&can, d, root) == hipSuccess && can) {
+      DeviceGuard guard(d);
+      (void)hipDeviceEnablePeerAccess(root, 0);
+    }
+    (void)hipGetLastError();  // "already enabled" is fine
+  }
+  *out = s;
+  return CPMPC_OK;
+}
+
+extern "C" int cpmpc_sharded_num_shards(const cpmpc_sharded* s) { return s ? (int)s->shards.size() : -1; }
+extern "C" int cpmpc_sharded_device(const cpmpc_sharded* s, int shard) {
+  return (s && shard >= 0 && shard < (int)s->shards.size()) ? s->shards[shard].device : -1;
+}
+extern "C" cpmpc_solver* cpmpc_sharded_handle(cpmpc_sharded* s, int shard) {
+  return (s && shard >= 0 && shard < (int)s->shards.size()) ? s->shards[shard].h : nullptr;
+}
+extern "C" int cpmpc_sharded_range(const cpmpc_sharded* s, int shard, int64_t B, int64_t* lo, int64_t* hi) {
+  if (!s || !lo || !hi || shard < 0 || shard >= (int)s->shards.size() || B < 0)
+    return fail(CPMPC_ERR_INVALID_ARG, "bad argument");
+  shard_range(B, shard, (int)s->shards.size(), lo, hi);
+  return CPMPC_OK;
+}
+extern "C" int cpmpc_sharded_reset(cpmpc_sharded* s) {
+  if (!s) return fail(CPMPC_ERR_INVALID_ARG, "null solver");
+  for (auto& sh : s->shards) cpmpc_reset(sh.h);
+  return CPMPC_OK;
+}
+
+static int sharded_check(const cpmpc_sharded* s, int64_t B) {
+  if (B < 1) return fail(CPMPC_ERR_INVALID_ARG, "B must be >= 1");
+  if (B > s->cap) return fail(CPMPC_ERR_BATCH, "B=%lld exceeds the capacity %lld given to cpmpc_sharded_create", (long long)B, (long long)s->cap);
+  return CPMPC_OK;
+}
+
+extern "C" int cpmpc_sharded_step_batch_host(cpmpc_sharded* s, int64_t B, const double* x0_host,
+                                             const double* dyn_shared_host, double set_point,
+                                             const cpmpc_step_host_outputs* out) {
+  if (!s || !x0_host || !dyn_shared_host || !out) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
+  if (!std::isfinite(set_point)) return fail(CPMPC_ERR_INVALID_ARG, "set_point must be finite");
+  int rc = sharded_check(s, B);
+  if (rc) return rc;
+  const int n = (int)s->shards.size();
+  // every shard's upload, kernels and download are queued on its own stream before anybody is waited for
+  int begun = 0;
+  for (int i = 0; i < n && rc == CPMPC_OK; ++i) {
+    int64_t lo, hi;
+    shard_range(B, i, n, &lo, &hi);
+    if (hi == lo) continue;
+    Shard& sh = s->shards[i];
+    DeviceGuard guard(sh.device);
+    CPMPC_DISPATCH(sh.h->dtype, sh.h->model,
+                   (rc = step_host_begin<R, M>(sh.h, hi - lo, x0_host, B, lo, dyn_shared_host, set_point,
+                                               out->predicted != nullptr, out->solution != nullptr)));
+    if (rc == CPMPC_OK) begun = i + 1;
+  }
+  int first_rc = rc;
+  for (int i = 0; i < begun; ++i) {   // also after a failure: drain what was started
+    int64_t lo, hi;
+    shard_range(B, i, n, &lo, &hi);
+    if (hi == lo) continue;
+    Shard& sh = s->shards[i];
+    DeviceGuard guard(sh.device);
+    int rc_i = CPMPC_OK;
+    if (first_rc == CPMPC_OK) {
+      CPMPC_DISPATCH(sh.h->dtype, sh.h->model, (rc_i = step_host_end<R, M>(sh.h, hi - lo, *out, B, lo)));
+      if (rc_i != CPMPC_OK) first_rc = rc_i;
+    } else {
+      (void)hipStreamSynchronize(sh.h->hstream);
+    }
+  }
+  return first_rc;
+}
+
+static int ensure_shard_buf(Shard& sh, size_t bytes) {
+  if (sh.buf_bytes >= bytes) return CPMPC_OK;
+  HIP_TRY(hipStreamSynchronize(sh.stream));
+  if (sh.buf) (void)hipFree(sh.buf);
+  sh.buf = nullptr;
+  sh.buf_bytes = 0;
+  HIP_TRY(hipMalloc(&sh.buf, bytes));
+  sh.buf_bytes = bytes;
+  return CPMPC_OK;
+}
+
+extern "C" int cpmpc_sharded_step_batch(cpmpc_sharded* s, int64_t B, const void* x0, const double* dyn_shared_host,
+                                        double set_point, const cpmpc_step_outputs* out, void* stream) {
+  if (!s || !x0 || !dyn_shared_host || !out) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
+  if (!std::isfinite(set_point)) return fail(CPMPC_ERR_INVALID_ARG, "set_point must be finite");
+  if (out->guess || out->solution || out->ls_evals)
+    return fail(CPMPC_ERR_UNSUPPORTED, "guess / solution / ls_evals are not gathered by the sharded step");
+  int rc = sharded_check(s, B);
+  if (rc) return rc;
+  const int n = (int)s->shards.size();
+  const size_t es = s->esize;
+  const hipStream_t root_stream = (hipStream_t)stream;
+  const int root = s->shards[0].device;
+  const size_t NX = (size_t)s->NX, N = (size_t)s->N;
+  // the caller's inputs are ready where its stream is now
+  {
+    DeviceGuard guard(root);
+    for (int i = 0; i < n; ++i) HIP_TRY(hipEventRecord(s->shards[i].ready, root_stream));
+  }
+  for (int i = 0; i < n; ++i) {
+    int64_t lo, hi;
+    shard_range(B, i, n, &lo, &hi);
+    if (hi == lo) continue;
+    const size_t Bs = (size_t)(hi - lo);
+    Shard& sh = s->shards[i];
+    DeviceGuard guard(sh.device);
+    // per-shard staging on the shard's own device, 256-byte aligned pieces
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_x0 = 0, o_u = al(NX * Bs * es), o_pred = o_u + al(N * Bs * es), o_cost = o_pred + al(N * NX * Bs * es),
+                 o_eq = o_cost + al(Bs * es), o_st = o_eq + al(Bs * es), o_it = o_st + al(Bs * 4), o_end = o_it + al(Bs * 4);
+    rc = ensure_shard_buf(sh, o_end);
+    if (rc) return rc;
+    char* b = (char*)sh.buf;
+    HIP_TRY(hipStreamWaitEvent(sh.stream, sh.ready, 0));
+    // scatter: my columns of x0 [NX][B] (root device) -> [NX][Bs] here
+    HIP_TRY(hipMemcpy2DAsync(b + o_x0, Bs * es, (const char*)x0 + (size_t)lo * es, (size_t)B * es, Bs * es, NX,
+                             hipMemcpyDefault, sh.stream));
+    cpmpc_step_inputs in;
+    memset(&in, 0, sizeof in);
+    in.x0 = b + o_x0;
+    in.dyn_shared_host = dyn_shared_host;
+    in.set_point_shared = set_point;
+    cpmpc_step_outputs o;
+    memset(&o, 0, sizeof o);
+    o.u = out->u ? b + o_u : nullptr;
+    o.predicted = out->predicted ? b + o_pred : nullptr;
+    o.final_cost = out->final_cost ? b + o_cost : nullptr;
+    o.final_eq_l1 = out->final_eq_l1 ? b + o_eq : nullptr;
+    o.status = out->status ? (int32_t*)(b + o_st) : nullptr;
+    o.iterations = out->iterations ? (int32_t*)(b + o_it) : nullptr;
+    rc = cpmpc_step_batch(sh.h, (int64_t)Bs, &in, &o, sh.stream);
+    if (rc) return rc;
+    // gather: rows of Bs scalars here -> rows of B scalars on the root device, at column lo
+    auto gather = [&](void* dst, const void* src, size_t rows, size_t e) -> hipError_t {
+      if (!dst) return hipSuccess;
+      return hipMemcpy2DAsync((char*)dst + (size_t)lo * e, (size_t)B * e, src, Bs * e, Bs * e, rows, hipMemcpyDefault,
+                              sh.stream);
+    };
+    HIP_TRY(gather(out->u, b + o_u, N, es));
+    HIP_TRY(gather(out->predicted, b + o_pred, N * NX, es));
+    HIP_TRY(gather(out->final_cost, b + o_cost, 1, es));
+    HIP_TRY(gather(out->final_eq_l1, b + o_eq, 1, es));
+    HIP_TRY(gather(out->status, b + o_st, 1, 4));
+    HIP_TRY(gather(out->iterations, b + o_it, 1, 4));
+    HIP_TRY(hipEventRecord(sh.done, sh.stream));
+  }
+  {
+    DeviceGuard guard(root);
+    for (int i = 0; i < n; ++i) {
+      int64_t lo, hi;
+      shard_range(B, i, n, &lo, &hi);
+      if (hi > lo) HIP_TRY(hipStreamWaitEvent(root_stream, s->shards[i].done, 0));
+    }
   }
   return CPMPC_OK;
 }
@@ -1029,6 +1339,7 @@ extern "C" int cpmpc_linearize_batch(cpmpc_solver* s, int64_t B, const double* d
   CPMPC_DISPATCH(s->dtype, s->model,
                  (linearize_batch_impl<R, M>(s, B, dyn_shared_host, z, c, Phi, Gamma, (hipStream_t)stream)));
   HIP_TRY(hipGetLastError());
+  track_caller_stream(s, (hipStream_t)stream);  // the step buffers of the workspace were used on the caller's stream
   return CPMPC_OK;
 }
 
@@ -1143,6 +1454,19 @@ extern "C" int cpmpc_debug_phase_cycles(unsigned long long* out8) {
     return -1;
   unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   hipMemcpyToSymbol(HIP_SYMBOL(cpmpc::g_fused_phase_cycles), zero, sizeof(zero));
+  return 0;
+}
+#endif
+
+#ifdef CPMPC_FUSED_CLOCK
+// debug build only: read and clear {sum of shader cycles, sum of 100 MHz ticks, waves, max cycles of a wave} of the
+// fused_sqp_kernel launches since the last call
+extern "C" int cpmpc_debug_kernel_clock(unsigned long long* out4) {
+  hipDeviceSynchronize();
+  if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(cpmpc::g_fused_clock), 4 * sizeof(unsigned long long)) != hipSuccess)
+    return -1;
+  unsigned long long zero[4] = {0, 0, 0, 0};
+  hipMemcpyToSymbol(HIP_SYMBOL(cpmpc::g_fused_clock), zero, sizeof(zero));
   return 0;
 }
 #endif

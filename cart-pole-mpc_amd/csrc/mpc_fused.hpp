@@ -142,6 +142,11 @@ __device__ __forceinline__ R group_last(R v, int gbase) {
 #ifndef CPMPC_FUSED_WAVES_F32
 #define CPMPC_FUSED_WAVES_F32 2
 #endif
+// 1 (default): the fp32 fused kernel also refines the terminal multipliers once through the factored operator (the
+// fp64 one always does); 0 builds the A/B variant without it (tools: build_variant("norefine32", ...))
+#ifndef CPMPC_FUSED_REFINE_F32
+#define CPMPC_FUSED_REFINE_F32 1
+#endif
 // unroll factor of the block-local sweep passes (LDS reads of several controls in flight)
 #ifndef CPMPC_SWEEP_UNROLL
 #define CPMPC_SWEEP_UNROLL 5
@@ -169,6 +174,31 @@ __device__ unsigned long long g_fused_phase_cycles[8];
 #define CPMPC_TICK_INIT() do { } while (0)
 #define CPMPC_TICK(IDX) do { } while (0)
 #define CPMPC_TICK_FLUSH() do { } while (0)
+#endif
+
+// Debug build only (-DCPMPC_FUSED_CLOCK): every wave stamps the shader clock (s_memtime) and the constant 100 MHz
+// counter (s_memrealtime) once on entry and once on exit; the sums over waves give the clock the part holds while this
+// kernel runs (MI355X_MICROARCH.md, DVFS give-back item 6).  The stamps go to a buffer of their own that nothing else
+// reads; read back by cpmpc_debug_kernel_clock().  Not part of the product library.
+#ifdef CPMPC_FUSED_CLOCK
+__device__ unsigned long long g_fused_clock[4];  // sum of shader cycles, sum of 100 MHz ticks, waves, max cycles
+#define CPMPC_CLOCK_BEGIN()                                                  \
+  const unsigned long long clk_c0 = __builtin_amdgcn_s_memtime();           \
+  const unsigned long long clk_r0 = __builtin_amdgcn_s_memrealtime()
+#define CPMPC_CLOCK_END()                                                                          \
+  do {                                                                                             \
+    const unsigned long long clk_c1 = __builtin_amdgcn_s_memtime();                                \
+    const unsigned long long clk_r1 = __builtin_amdgcn_s_memrealtime();                            \
+    if (threadIdx.x == 0) {                                                                        \
+      atomicAdd(&g_fused_clock[0], clk_c1 - clk_c0);                                               \
+      atomicAdd(&g_fused_clock[1], clk_r1 - clk_r0);                                               \
+      atomicAdd(&g_fused_clock[2], 1ull);                                                          \
+      atomicMax(&g_fused_clock[3], clk_c1 - clk_c0);                                               \
+    }                                                                                              \
+  } while (0)
+#else
+#define CPMPC_CLOCK_BEGIN() do { } while (0)
+#define CPMPC_CLOCK_END() do { } while (0)
 #endif
 
 // SHARED: the batch shares one parameter set -> the model constants stay wave-uniform (scalar registers)

@@ -793,8 +793,10 @@ __global__ CPMPC_QPLS_BOUNDS void qp_ls_kernel(const SolverArgs<R, M> a) {
     for (int i = 0; i < NX; ++i) rhs[i] = hv[i] - rho[i];
     ldl_solve(rhs, q);
     // One step of iterative refinement of q with the residual taken through the factored operator
-    // (S = W^T D^-1 W is a normal-equations matrix; see mpc_fused_body.inc).  fp64 only: in fp32 the rest of the
-    // pipeline rounds far above what this recovers, and the extra pass over W is HBM traffic here.
+    // (S = W^T D^-1 W is a normal-equations matrix; see mpc_fused_body.inc).  fp64 only HERE: this kernel is bound by
+    // its workspace traffic and the pass re-reads W and T from HBM (+25 % bytes); the fused kernel, where the pass is
+    // on-chip, refines in fp32 too, so the two fp32 pipelines differ by that one correction (both are fp32-rounding
+    // level; the parity dtype is fp64, where both refine).
     if constexpr (sizeof(R) == 8) {
       R acc[NX];
 #pragma unroll

@@ -32,7 +32,9 @@ std::string NLSSolverOutputs::ToString() const {
   return os.str();
 }
 
-static cpmpc_params ToC(const OptimizationParams& p) {
+cpmpc_params ToCParams(const OptimizationParams& p);  // also used by sharded_optimization.cc
+static cpmpc_params ToC(const OptimizationParams& p) { return ToCParams(p); }
+cpmpc_params ToCParams(const OptimizationParams& p) {
   cpmpc_params c;
   c.control_dt = p.control_dt;
   c.window_length = p.window_length;
@@ -111,6 +113,17 @@ OptimizationOutputs Optimization::Step(const SingleCartPoleState& current_state,
 
   previous_solution_ = std::move(z);  // optimization.cc:85
   return out;
+}
+
+void Optimization::StepBatchInto(const double* states_soa, std::size_t B, const SingleCartPoleParams& dynamics_params,
+                                 double b_x_set_point, double* u, double* predicted_states, std::int32_t* status,
+                                 std::int32_t* iterations, double* final_cost, double* final_equality_l1) {
+  if (states_soa == nullptr || B == 0) throw std::invalid_argument("StepBatch: states_soa must be [4][B], B >= 1");
+  if (B > max_batch_) throw std::invalid_argument("StepBatch: batch exceeds the capacity given at construction");
+  const auto dyn = dynamics_params.ToArray();
+  const int rc = cpmpc_step_batch_host(solver_, static_cast<std::int64_t>(B), states_soa, dyn.data(), b_x_set_point, u,
+                                       predicted_states, status, iterations, final_cost, final_equality_l1);
+  if (rc != CPMPC_OK) Throw(rc);
 }
 
 BatchOptimizationOutputs Optimization::StepBatch(const std::vector<double>& states_soa,

@@ -95,6 +95,12 @@ class Optimization {
                                                    const SingleCartPoleParams& dynamics_params,
                                                    double b_x_set_point);
 
+  // The same writing straight into caller-owned arrays ([N][B], [N][4][B], [B] ...; any output pointer may be null):
+  // what the numpy entry point of pypendulum uses, no per-element conversion on either side.
+  void StepBatchInto(const double* states_soa, std::size_t B, const SingleCartPoleParams& dynamics_params,
+                     double b_x_set_point, double* u, double* predicted_states, std::int32_t* status,
+                     std::int32_t* iterations, double* final_cost, double* final_equality_l1);
+
   // Discard previous initial guess, which will reset the problem (optimization.hpp:83).
   void Reset();
 

@@ -1,18 +1,58 @@
 // pypendulum.cc -- Python module `pypendulum` with the names of the reference's nanobind wrapper
 // (wrapper/wrapper.cc:40-98), bound with pybind11 over the C++ facade (nanobind is not available
-// in this image).  Additions, all batched: Optimization(params, max_batch), .step_batch(),
+// in this image).  Additions, all batched: Optimization(params, max_batch), .step_batch() (numpy arrays in and out,
+// written by the C-ABI without per-element conversion), ShardedOptimization (several GPUs from one process),
 // .reset(); Simulator.set_state(); and the JSON wire format of the reference's browser build (wasm.cc:19-65):
 // X.to_json() / X.from_json(text) on every struct, OptimizationOutputs.{get_log, window_length, get_control,
 // get_predicted_state} with the names of wasm.cc:86-105 in snake_case.
+#include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
 #include "json.hpp"
 #include "optimization.hpp"
+#include "sharded_optimization.hpp"
 #include "simulator.hpp"
 
 namespace py = pybind11;
 using namespace pendulum;
+
+// Batched outputs as numpy arrays (what step_batch returns): u [N, B], predicted_states [N, 4, B], the rest [B].
+struct BatchArrays {
+  std::size_t batch{0};
+  py::array_t<double> u, predicted_states, final_cost, final_equality_l1;
+  py::array_t<std::int32_t> status, iterations;
+};
+
+// states: a C-contiguous float64 array [4, B] (anything else is converted once by numpy).  The output arrays are
+// allocated here and the C-ABI writes straight into them: no Python objects per element on either side (at
+// B = 262 144 the list-based binding of round 2 boxed about 10^7 doubles per call).
+template <typename Opt>
+static BatchArrays StepBatchArrays(Opt& self, py::array_t<double, py::array::c_style | py::array::forcecast> states,
+                                   const SingleCartPoleParams& dyn, double set_point, bool want_predicted) {
+  if (states.ndim() != 2 || states.shape(0) != 4 || states.shape(1) < 1)
+    throw std::invalid_argument("step_batch: states must be a [4, B] array");
+  const std::size_t B = static_cast<std::size_t>(states.shape(1));
+  const std::size_t N = self.params().window_length;
+  BatchArrays out;
+  out.batch = B;
+  out.u = py::array_t<double>({N, B});
+  if (want_predicted) out.predicted_states = py::array_t<double>({N, std::size_t{4}, B});
+  out.status = py::array_t<std::int32_t>(B);
+  out.iterations = py::array_t<std::int32_t>(B);
+  out.final_cost = py::array_t<double>(B);
+  out.final_equality_l1 = py::array_t<double>(B);
+  const double* x = states.data();
+  double* u = out.u.mutable_data();
+  double* pred = want_predicted ? out.predicted_states.mutable_data() : nullptr;
+  std::int32_t *st = out.status.mutable_data(), *it = out.iterations.mutable_data();
+  double *fc = out.final_cost.mutable_data(), *fe = out.final_equality_l1.mutable_data();
+  {
+    py::gil_scoped_release release;  // the GPU round trip does not need the interpreter
+    self.StepBatchInto(x, B, dyn, set_point, u, pred, st, it, fc, fe);
+  }
+  return out;
+}
 
 PYBIND11_MODULE(pypendulum, m) {
   m.doc() = "cart-pole MPC (MI355X-native hot path); API of gareth-cross/cart-pole-mpc's pypendulum";
@@ -101,9 +141,30 @@ PYBIND11_MODULE(pypendulum, m) {
       .def(py::init<const OptimizationParams&, std::size_t, int>(), py::arg("params"), py::arg("max_batch"),
            py::arg("device") = 0)
       .def("step", &Optimization::Step)
-      .def("step_batch", &Optimization::StepBatch)
+      .def("step_batch", &StepBatchArrays<Optimization>, py::arg("states"), py::arg("dynamics_params"),
+           py::arg("b_x_set_point"), py::arg("want_predicted") = true)
+      .def("step_batch_lists", &Optimization::StepBatch)  // round 2's element-by-element form, kept for comparison
       .def("reset", &Optimization::Reset)
       .def("set_previous_solution", &Optimization::SetPreviousSolution);
+
+  py::class_<BatchArrays>(m, "BatchArrays")
+      .def_readonly("batch", &BatchArrays::batch)
+      .def_readonly("u", &BatchArrays::u)
+      .def_readonly("predicted_states", &BatchArrays::predicted_states)
+      .def_readonly("status", &BatchArrays::status)
+      .def_readonly("iterations", &BatchArrays::iterations)
+      .def_readonly("final_cost", &BatchArrays::final_cost)
+      .def_readonly("final_equality_l1", &BatchArrays::final_equality_l1);
+
+  py::class_<ShardedOptimization>(m, "ShardedOptimization")
+      .def(py::init<const OptimizationParams&, std::size_t, const std::vector<int>&>(), py::arg("params"),
+           py::arg("max_batch"), py::arg("devices") = std::vector<int>{})
+      .def("step_batch", &StepBatchArrays<ShardedOptimization>, py::arg("states"), py::arg("dynamics_params"),
+           py::arg("b_x_set_point"), py::arg("want_predicted") = true)
+      .def("reset", &ShardedOptimization::Reset)
+      .def("num_shards", &ShardedOptimization::NumShards)
+      .def("device_of_shard", &ShardedOptimization::DeviceOfShard)
+      .def("shard_range", &ShardedOptimization::ShardRange);
 
   py::class_<Vector2>(m, "Vector2")
       .def(py::init<double, double>())

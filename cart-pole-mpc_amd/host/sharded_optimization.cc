@@ -1,0 +1,79 @@
+// sharded_optimization.cc -- pendulum::ShardedOptimization over cpmpc_sharded_* (include/cpmpc.h).
+#include "sharded_optimization.hpp"
+
+#include <stdexcept>
+#include <string>
+
+#include "../../include/cpmpc.h"
+
+namespace pendulum {
+
+cpmpc_params ToCParams(const OptimizationParams& p);  // optimization.cc
+
+[[noreturn]] static void ThrowSharded(int rc) {
+  const std::string text = std::string("cpmpc: ") + cpmpc_last_error();
+  if (rc == CPMPC_ERR_INVALID_ARG) throw std::invalid_argument(text);
+  throw std::runtime_error(text);
+}
+
+ShardedOptimization::ShardedOptimization(const OptimizationParams& params, std::size_t max_batch,
+                                         const std::vector<int>& devices)
+    : params_(params), max_batch_(max_batch) {
+  const cpmpc_params c = ToCParams(params);
+  const int rc = cpmpc_sharded_create(&c, nullptr, CPMPC_F64, static_cast<std::int64_t>(max_batch),
+                                      devices.empty() ? nullptr : devices.data(), static_cast<int>(devices.size()),
+                                      &sharded_);
+  if (rc != CPMPC_OK) ThrowSharded(rc);
+}
+
+ShardedOptimization::~ShardedOptimization() { cpmpc_sharded_destroy(sharded_); }
+
+void ShardedOptimization::Reset() { cpmpc_sharded_reset(sharded_); }
+
+std::size_t ShardedOptimization::NumShards() const noexcept {
+  return static_cast<std::size_t>(cpmpc_sharded_num_shards(sharded_));
+}
+int ShardedOptimization::DeviceOfShard(std::size_t shard) const noexcept {
+  return cpmpc_sharded_device(sharded_, static_cast<int>(shard));
+}
+std::pair<std::size_t, std::size_t> ShardedOptimization::ShardRange(std::size_t shard, std::size_t B) const {
+  std::int64_t lo = 0, hi = 0;
+  const int rc = cpmpc_sharded_range(sharded_, static_cast<int>(shard), static_cast<std::int64_t>(B), &lo, &hi);
+  if (rc != CPMPC_OK) ThrowSharded(rc);
+  return {static_cast<std::size_t>(lo), static_cast<std::size_t>(hi)};
+}
+
+void ShardedOptimization::StepBatchInto(const double* states_soa, std::size_t B,
+                                        const SingleCartPoleParams& dynamics_params, double b_x_set_point, double* u,
+                                        double* predicted_states, std::int32_t* status, std::int32_t* iterations,
+                                        double* final_cost, double* final_equality_l1) {
+  if (states_soa == nullptr || B == 0) throw std::invalid_argument("StepBatch: states_soa must be [4][B], B >= 1");
+  if (B > max_batch_) throw std::invalid_argument("StepBatch: batch exceeds the capacity given at construction");
+  const auto dyn = dynamics_params.ToArray();
+  const cpmpc_step_host_outputs ho = {u, predicted_states, status, iterations, final_cost, final_equality_l1, nullptr};
+  const int rc = cpmpc_sharded_step_batch_host(sharded_, static_cast<std::int64_t>(B), states_soa, dyn.data(),
+                                               b_x_set_point, &ho);
+  if (rc != CPMPC_OK) ThrowSharded(rc);
+}
+
+BatchOptimizationOutputs ShardedOptimization::StepBatch(const std::vector<double>& states_soa,
+                                                        const SingleCartPoleParams& dynamics_params,
+                                                        const double b_x_set_point) {
+  if (states_soa.empty() || states_soa.size() % 4 != 0)
+    throw std::invalid_argument("StepBatch: states_soa must be [4][B]");
+  const std::size_t B = states_soa.size() / 4;
+  const std::size_t N = params_.window_length;
+  BatchOptimizationOutputs out;
+  out.batch = B;
+  out.u.resize(N * B);
+  out.predicted_states.resize(4 * N * B);
+  out.status.resize(B);
+  out.iterations.resize(B);
+  out.final_cost.resize(B);
+  out.final_equality_l1.resize(B);
+  StepBatchInto(states_soa.data(), B, dynamics_params, b_x_set_point, out.u.data(), out.predicted_states.data(),
+                out.status.data(), out.iterations.data(), out.final_cost.data(), out.final_equality_l1.data());
+  return out;
+}
+
+}  // namespace pendulum

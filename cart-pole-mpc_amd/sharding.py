@@ -81,3 +81,15 @@ def max_over_ranks(value, device):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def all_ranks(values, device):
+    """Every rank's list of python floats, on every rank: [[rank 0's values], [rank 1's], ...] (per-rank timings for
+    the benchmark line; one small all-gather outside the timed region)."""
+    vals = [float(v) for v in values]
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [vals]
+    t = torch.tensor(vals, dtype=torch.float64, device=device)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [[float(x) for x in o.cpu().tolist()] for o in out]

@@ -256,6 +256,37 @@ int cpmpc_sim_step_batch_model(int model, int dtype, int64_t B, const double* dy
 int cpmpc_sim_step_batch_host(int64_t B, const double* dyn_shared_host, double dt,
                               const double* u_host, const double* fext_host, double* state_host);
 
+/* ---- several GPUs from ONE process ------------------------------------------------------------------ */
+/* The reference is single-threaded and single-device; a batch of independent controllers shards
+ * embarrassingly, so this is new surface: one `cpmpc_sharded` owns one solver handle + one stream per shard, a shard
+ * living on one HIP device.  A step splits the batch contiguously (shard i owns columns
+ * [i*B/n + min(i, B%n), ...) -- the same rule as cart-pole-mpc_amd/sharding.py: shard_range), runs every shard
+ * concurrently, and assembles the outputs in global problem order.  No data-path collective: the only traffic between
+ * devices is the scatter of x0 and the gather of the results, point-to-point copies to/from the root device (shard 0's)
+ * over xGMI, or through each shard's pinned staging for the host-pointer call.  `devices` may name a device more than
+ * once (two shards on one GPU: how the tests run it on a one-GPU box; results are bitwise those of one handle).
+ * pendulum::ShardedOptimization (cart-pole-mpc_amd/host/sharded_optimization.hpp) is the C++ class over it. */
+typedef struct cpmpc_sharded cpmpc_sharded;
+/* devices == NULL: every visible gfx950 device, one shard each (n_devices ignored).  max_batch is the TOTAL batch. */
+int cpmpc_sharded_create(const cpmpc_params* params, const cpmpc_solver_opts* opts /*nullable*/, int dtype,
+                         int64_t max_batch, const int* devices, int n_devices, cpmpc_sharded** out);
+void cpmpc_sharded_destroy(cpmpc_sharded* s);
+int cpmpc_sharded_num_shards(const cpmpc_sharded* s);
+int cpmpc_sharded_device(const cpmpc_sharded* s, int shard);          /* HIP device of a shard; -1 if out of range */
+cpmpc_solver* cpmpc_sharded_handle(cpmpc_sharded* s, int shard);      /* the shard's own solver (options, profiling) */
+/* columns [*lo, *hi) of a B-problem batch that shard `shard` solves */
+int cpmpc_sharded_range(const cpmpc_sharded* s, int shard, int64_t B, int64_t* lo, int64_t* hi);
+int cpmpc_sharded_reset(cpmpc_sharded* s);                             /* Optimization::Reset on every shard */
+/* cpmpc_step_batch_host_ex over all shards: HOST arrays in the global layouts ([4][B] in, [N][B] etc. out). */
+int cpmpc_sharded_step_batch_host(cpmpc_sharded* s, int64_t B, const double* x0_host, const double* dyn_shared_host,
+                                  double set_point, const cpmpc_step_host_outputs* out);
+/* cpmpc_step_batch over all shards with the data resident in HBM: x0 [4][B] and every non-NULL output ([N][B] u,
+ * [N][4][B] predicted, [B] status / iterations / final_cost / final_eq_l1; guess / ls_evals / solution are not gathered)
+ * live on the ROOT device (shard 0's), in the handle's dtype.  Asynchronous on `stream` (a stream of the root
+ * device): slices travel to and from the other shards' devices by peer copies ordered with events. */
+int cpmpc_sharded_step_batch(cpmpc_sharded* s, int64_t B, const void* x0, const double* dyn_shared_host,
+                             double set_point, const cpmpc_step_outputs* out, void* stream);
+
 /* ---- measurement ------------------------------------------------------------------------------ */
 
 enum {

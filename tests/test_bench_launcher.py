@@ -47,6 +47,48 @@ def test_launcher_spawns_world_of_two(monkeypatch):
     assert line["n_gpus"] == 2 and line["world_size_seen"] == 2
     assert line["gathered"] == [4, 192] and line["in_global_order"]
     assert line["local_ranks"] == [0, 1] and line["max_rank"] == 1.0
+    assert line["per_rank"] == [[0.0, 0.0], [1.0, 10.0]]      # every rank's own timings reach the line
+
+
+def test_a_rank_that_dies_ends_the_run_at_once(monkeypatch):
+    """a non-zero rank that dies early must not leave rank 0 waiting in a collective until its timeout
+    (the stub's other ranks sleep 120 s): the launcher polls all ranks, kills the rest and returns that exit code."""
+    import time
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    for failing in (1, 0):
+        monkeypatch.setenv("CPMPC_STUB_FAIL_RANK", str(failing))
+        t0 = time.monotonic()
+        rc, _ = bench.launch_ranks(2, ["--gpus", "2"], n_devices=2, script=STUB, timeout=300)
+        assert rc == 3 and time.monotonic() - t0 < 60
+
+
+def test_launcher_overall_timeout(monkeypatch):
+    import time
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setenv("CPMPC_STUB_FAIL_RANK", "99")       # nobody fails, everybody sleeps
+    t0 = time.monotonic()
+    rc, _ = bench.launch_ranks(2, ["--gpus", "2"], n_devices=2, script=STUB, timeout=20)
+    assert rc == 124 and time.monotonic() - t0 < 60
+
+
+def test_gpu_count_comes_from_sysfs_not_from_the_runtime(tmp_path, monkeypatch):
+    """The launcher parent counts GPUs in the KFD topology (sysfs): no HIP call, no torch.cuda in that process."""
+    for i, simd in enumerate((0, 0, 1024, 1024, 1024)):      # two CPU nodes, three GPUs
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / "properties").write_text("cpu_cores_count %d\nsimd_count %d\nmem_banks_count 1\n" % (64 if simd == 0 else 0, simd))
+    assert bench.kfd_gpu_nodes(str(tmp_path)) == 3
+    assert bench.kfd_gpu_nodes(str(tmp_path / "missing")) is None
+    import inspect
+    src = inspect.getsource(bench.visible_gpus) + inspect.getsource(bench.kfd_gpu_nodes) + inspect.getsource(bench.launch_ranks)
+    assert "import torch" not in src.replace('"import torch; print(torch.cuda.device_count())"', "")
+    monkeypatch.setattr(bench, "kfd_gpu_nodes", lambda root=None: 8)
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "2,3")
+    assert bench.visible_gpus() == 2
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    monkeypatch.delenv("CUDA_VISIBLE_DEVICES", raising=False)
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
+    assert bench.visible_gpus() == 8
 
 
 def test_world_size_mismatch_fails_loudly():

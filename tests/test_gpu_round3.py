@@ -1,0 +1,225 @@
+"""Round-3 GPU tests: the multi-GPU path as far as one GPU can prove it (RCCL branch in a world of one; rank 7 of 8's
+full shard of BASELINE configs[3]; several shards from one C++ process), stream ordering of the host-pointer entry
+points, and KKT residuals of GPU solutions at batch scale."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import DYN_UI, ROOT, random_states
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+DEV = "cuda:0"
+NO_TOL = dict(max_iterations=5, relative_exit_tol=0.0, absolute_first_derivative_tol=0.0)
+LIB_DIR = os.path.join(ROOT, "cart-pole-mpc_amd", "lib")
+
+
+def T(a, dtype=torch.float64):
+    return torch.tensor(np.ascontiguousarray(a), dtype=dtype, device=DEV)
+
+
+def _bench(args, env_extra=None, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+# ------------------------------------------------------------------------------------------------
+# e: multi-GPU
+# ------------------------------------------------------------------------------------------------
+def test_rccl_branch_in_a_world_of_one():
+    """The code a rank of `bench.py --gpus 8` runs -- nccl process group on its device, ResultGather on device
+    tensors, barrier, max-reduce of the time, per-rank all-gather -- executed in a world of one
+    (CPMPC_BENCH_FORCE_DIST=1), so that RCCL code does not run for the first time in the driver's scaling run."""
+    line = _bench(["--gpus", "1", "--batch", "8192", "--steps", "3", "--warmup", "1", "--no-fp64", "--no-variants",
+                   "--no-cpu-baseline"], {"CPMPC_BENCH_FORCE_DIST": "1", "MASTER_PORT": "29533"})
+    d = line["distributed"]
+    assert d["backend"] == "nccl" and d["world_size_seen"] == 1
+    assert line["gathered"]["shape"] == [40, 8192] and line["gathered"]["own_block_intact"]
+    assert d["gather_ms"] is not None and d["gather_ms"] > 0
+    pr = d["per_rank"]
+    assert len(pr["ms_per_step_own"]) == 1 and pr["ms_per_step_own_min"] == pr["ms_per_step_own_max"] > 0
+    assert pr["sqp_kernel_ms_per_launch"][0] > 0 and pr["gather_ms"][0] > 0
+    assert pr["ms_per_step_own"][0] <= line["ms_per_step"] * 1.05
+    assert line["n_gpus"] == 1 and line["value"] > 0
+
+
+def test_rank_7_of_8_solves_its_full_shard_of_configs3():
+    """BASELINE configs[3] is 2 097 152 problems over 8 GPUs: rank 7's share is columns 1 835 008 .. 2 097 151 of the one
+    seeded global batch.  `bench.py --as-rank 7 --of 8` solves exactly that shard at full per-GPU size on this GPU (no
+    process group), in the parity dtype, and 512 lanes sampled across it are held to the oracle."""
+    line = _bench(["--as-rank", "7", "--of", "8", "--dtype", "f64", "--steps", "2", "--warmup", "1", "--parity-lanes", "512"])
+    a = line["as_rank"]
+    assert a["rank"] == 7 and a["of"] == 8 and a["columns_of_global_batch"] == [1835008, 2097152]
+    assert line["config"]["global_batch"] == 2097152 and line["config"]["batch_per_gpu"] == 262144
+    assert "configs[3]" in line["config"]["workload"] and "rank 7 of 8" in line["config"]["workload"]
+    assert line["status_histogram"] == {"MAX_ITERATIONS": 262144}
+    p = a["parity"]
+    assert p["lanes"] >= 500 and p["lanes_over_1e-5"] == 0 and p["status_agree"] == p["lanes"], p
+    assert p["global_columns_first_last"] == [1835008, 2097151]
+    assert line["n_gpus"] == 1 and line["value"] > 1e6
+
+
+def test_shards_of_one_global_batch_do_not_depend_on_the_world_size(pkg):
+    """Rank r's problems are columns of ONE seeded batch: what rank 3 of 4 solves at 512 per GPU are columns 1536..2047
+    of the same 2048 a single GPU would solve, bitwise."""
+    import bench
+    sharding = __import__("importlib").import_module("cart-pole-mpc_amd.sharding")
+    total = 2048
+    full = bench.synth_states(bench.SEED, total)
+    opt = pkg.BatchOptimization(pkg.default_params(**NO_TOL), max_batch=total, dtype=torch.float64, device=0)
+    u_full = opt.step(T(full), DYN_UI, 0.0).u.clone()
+    lo, hi = sharding.shard_range(total, 3, 4)
+    part = bench.synth_states(bench.SEED, total, lo, hi)
+    small = pkg.BatchOptimization(pkg.default_params(**NO_TOL), max_batch=hi - lo, dtype=torch.float64, device=0)
+    assert torch.equal(small.step(T(part), DYN_UI, 0.0).u, u_full[:, lo:hi])
+
+
+def test_sharded_optimization_cpp_three_shards_on_one_device():
+    """pendulum::ShardedOptimization (one C++ process, one handle + stream per shard; include/cpmpc.h cpmpc_sharded_*)
+    with three shards on device 0 against one pendulum::Optimization: bitwise, ragged split, warm starts, Reset."""
+    r = subprocess.run([os.path.join(LIB_DIR, "sharded_smoke"), "0", "0", "0"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK sharded" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    r = subprocess.run([os.path.join(LIB_DIR, "sharded_smoke")], capture_output=True, text=True, timeout=600)  # all visible
+    assert r.returncode == 0 and "OK sharded" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_sharded_step_with_data_resident_on_the_root_device(pkg):
+    """cpmpc_sharded_step_batch: x0 and the outputs live on the root device, slices travel by peer copies ordered with
+    events.  Two shards on device 0, fp32 and fp64, ragged B: bitwise the single handle's u / predicted / status."""
+    import ctypes as C
+    lib = pkg.capi.load()
+    rng = np.random.default_rng(5)
+    for dtype, cdt in ((torch.float64, pkg.capi.F64), (torch.float32, pkg.capi.F32)):
+        B = 3001
+        x0 = T(random_states(rng, B), dtype)
+        ref = pkg.BatchOptimization(pkg.default_params(**NO_TOL), max_batch=B, dtype=dtype, device=0).step(x0, DYN_UI, 0.0)
+        params = pkg.default_params(**NO_TOL)
+        devs = (C.c_int * 2)(0, 0)
+        h = C.c_void_p()
+        pkg.capi.check(lib.cpmpc_sharded_create(C.byref(params), None, cdt, B, devs, 2, C.byref(h)))
+        try:
+            u = torch.full((40, B), float("nan"), dtype=dtype, device=DEV)
+            pred = torch.full((40, 4, B), float("nan"), dtype=dtype, device=DEV)
+            status = torch.full((B,), -1, dtype=torch.int32, device=DEV)
+            outs = pkg.capi.StepOutputs()
+            outs.u, outs.predicted, outs.status = u.data_ptr(), pred.data_ptr(), status.data_ptr()
+            dyn = (C.c_double * 9)(*DYN_UI)
+            stream = torch.cuda.current_stream().cuda_stream
+            pkg.capi.check(lib.cpmpc_sharded_step_batch(h, B, x0.data_ptr(), dyn, 0.0, C.byref(outs), stream))
+            torch.cuda.synchronize()
+            assert torch.equal(u, ref.u) and torch.equal(pred, ref.predicted_states) and torch.equal(status, ref.status)
+        finally:
+            lib.cpmpc_sharded_destroy(h)
+
+
+def test_pypendulum_step_batch_takes_and_returns_numpy_arrays(pkg):
+    """pypendulum's batched entry takes numpy arrays; the C-ABI writes straight into the returned ones."""
+    pyp = pkg.pypendulum()
+    rng = np.random.default_rng(9)
+    B = 20000
+    x0 = random_states(rng, B)
+    op = pyp.OptimizationParams()
+    op.max_iterations = 5
+    op.relative_exit_tol = 0.0
+    op.absolute_first_derivative_tol = 0.0
+    dyn = pyp.SingleCartPoleParams(*DYN_UI)
+    out = pyp.Optimization(op, B).step_batch(x0, dyn, 0.0)
+    assert isinstance(out.u, np.ndarray) and out.u.shape == (40, B) and out.u.dtype == np.float64
+    assert out.predicted_states.shape == (40, 4, B) and out.status.shape == (B,) and out.status.dtype == np.int32
+    ref = pkg.BatchOptimization(pkg.default_params(**NO_TOL), max_batch=B, dtype=torch.float64, device=0).step(T(x0), DYN_UI, 0.0)
+    assert np.array_equal(out.u, ref.u.cpu().numpy()) and np.array_equal(out.status, ref.status.cpu().numpy())
+    sh = pyp.ShardedOptimization(op, B, [0, 0]).step_batch(x0, dyn, 0.0, want_predicted=False)
+    assert np.array_equal(sh.u, out.u) and sh.predicted_states.size == 0
+    with pytest.raises(ValueError):
+        pyp.Optimization(op, 8).step_batch(np.zeros((3, 8)), dyn, 0.0)
+
+
+# ------------------------------------------------------------------------------------------------
+# a caller-stream read of the warm start followed at once by a host-pointer step
+# ------------------------------------------------------------------------------------------------
+def test_get_solution_on_a_side_stream_then_host_step(pkg):
+    """cpmpc_get_solution reads zx/zu on the caller's stream; a host-pointer step that follows immediately runs on
+    the handle's own stream and overwrites them.  The read must come out as the solution BEFORE that step (write-
+    after-read ordering through the handle's event), however busy the side stream is."""
+    import ctypes as C
+    lib = pkg.capi.load()
+    rng = np.random.default_rng(3)
+    B = 65536
+    x0 = random_states(rng, B)
+    opt = pkg.BatchOptimization(pkg.default_params(**NO_TOL), max_batch=B, dtype=torch.float64, device=0)
+    h = opt._h
+    N, dim = 40, 60
+    u_host = np.zeros((N, B))
+    status = np.zeros(B, dtype=np.int32)
+    dyn = (C.c_double * 9)(*DYN_UI)
+
+    def host_step(x):
+        x = np.ascontiguousarray(x)
+        pkg.capi.check(lib.cpmpc_step_batch_host(h, B, x.ctypes.data_as(C.POINTER(C.c_double)), dyn, 0.0,
+                                                 u_host.ctypes.data_as(C.POINTER(C.c_double)), None,
+                                                 status.ctypes.data_as(C.POINTER(C.c_int32)), None, None, None))
+    host_step(x0)                           # creates the handle's stream; the warm start now holds solution #1
+    z1 = opt.get_solution(B).clone()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    for rep in range(3):
+        z_side = torch.empty((dim, B), dtype=torch.float64, device=DEV)
+        with torch.cuda.stream(side):
+            big = torch.randn(4096, 4096, device=DEV)
+            for _ in range(20):             # keep the side stream busy so that the read below is still queued ...
+                big = big @ big * 1e-3
+            pkg.capi.check(lib.cpmpc_get_solution(h, B, C.c_void_p(z_side.data_ptr()), C.c_void_p(side.cuda_stream)))
+        host_step(x0 + 0.01 * (rep + 1))    # ... when this step starts overwriting zx/zu on the handle's stream
+        torch.cuda.synchronize()
+        assert torch.equal(z_side, z1), "get_solution on the side stream saw the next step's writes (rep %d)" % rep
+        z1 = opt.get_solution(B).clone()
+        torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------------------------------------
+# a9: KKT residuals of GPU solutions at batch scale, through the oracle's problem evaluation
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("pipeline", ["fused", "split"])
+def test_kkt_residual_of_gpu_solutions(pkg, orc, pipeline):
+    """4096 problems (half near-upright, half the benchmark's swing-up distribution) run on the GPU until they stop
+    moving; the returned z (cpmpc_get_solution) is put through the oracle's orc_problem_eval: on every lane that closed
+    its defects the gradient of the Lagrangian vanishes (least-squares multipliers), i.e. the GPU's answers are KKT
+    points of the problem of optimization.cc:194-301, not merely close to the oracle's iterates."""
+    rng = np.random.default_rng(11)
+    B = 4096
+    x0 = random_states(rng, B)
+    x0[:, ::2] = np.stack([rng.uniform(-0.3, 0.3, B // 2), np.pi / 2 + rng.uniform(-0.4, 0.4, B // 2),
+                           rng.uniform(-0.5, 0.5, B // 2), rng.uniform(-1, 1, B // 2)])
+    over = dict(max_iterations=300, relative_exit_tol=0.0, absolute_first_derivative_tol=0.0)
+    opt = pkg.BatchOptimization(pkg.default_params(**over), max_batch=B, dtype=torch.float64, device=0)
+    opt.set_pipeline(pipeline)
+    out = opt.step(T(x0), DYN_UI, 0.0)
+    z = opt.get_solution(B).cpu().numpy()
+    p = orc.default_opt_params(**over)
+    grad = np.zeros(B)
+    eq = np.zeros(B)
+    gnorm = np.zeros(B)
+    for b in range(B):
+        r, c, J, A = orc.problem_eval(p, DYN_UI, x0[:, b], 0.0, 0.0, z[:, b])
+        g = J.T @ r
+        lam = np.linalg.lstsq(A.T, -g, rcond=None)[0]
+        grad[b] = np.abs(g + A.T @ lam).max()
+        gnorm[b] = np.abs(g).max()
+        eq[b] = np.abs(c).sum()
+    feasible = eq < 1e-9
+    kkt = grad / (1.0 + gnorm)
+    print("%s: lanes with closed defects %d of %d (near-upright %d of %d); relative |grad L| on them: median %.1e max %.1e"
+          % (pipeline, feasible.sum(), B, feasible[::2].sum(), B // 2, np.median(kkt[feasible]), kkt[feasible].max()))
+    assert feasible[::2].all()                       # every near-upright problem converges
+    assert feasible.mean() > 0.9
+    assert (kkt[feasible] < 1e-6).mean() > 0.99      # a stalled flat optimum (test_converged_golden.py) may sit above
+    assert kkt[feasible].max() < 1e-3

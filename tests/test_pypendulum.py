@@ -215,8 +215,8 @@ def test_closed_loop_through_pypendulum(pp, orc):
 
 @pytest.mark.gpu
 def test_cpp_closed_loop_binary():
-    """The reference's closed-loop gtest (optimization_test.cc:12-77) compiled against this repo's
-    pendulum::Optimization / Simulator (tests/host/closed_loop_like_reference.cc)."""
+    """A C++ caller of this repo's pendulum::Optimization / Simulator (tests/host/facade_closed_loop.cc): swing-up and
+    balance in closed loop with the configuration and acceptance numbers of optimization_test.cc:13-20,44-66."""
     r = subprocess.run([os.path.join(LIB_DIR, "host_smoke")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "OK closed loop" in r.stdout
