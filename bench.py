@@ -341,6 +341,67 @@ def roofline_of(prof, dtype, B, iters, steps, rate_per_gpu):
     }
 
 
+# Issue cost of one wave64 vector instruction on one SIMD when enough waves share it (cycles; tools/ubench/clock.hip on
+# MI355X, profiles/r03_clock_ubench.jsonl: wall-clock rates at 8 waves per SIMD; the guide's figures are 2 / 8 for the
+# 32-bit classes).  Used only to express measured cycles as a fraction of the part's issue ceiling.
+ISSUE_CYCLES = {"f32_arith": 2.0, "other_32bit": 2.0, "f32_trans": 8.0, "f64_arith": 4.0, "f64_trans": 16.0}
+
+
+def clock_leg(B, timeout=600):
+    """The shader clock the part holds while fused_sqp_kernel runs this workload, and the cycles a wave spends in it:
+    tools/kernel_clock.py in a child process on the diagnostic build (-DCPMPC_FUSED_CLOCK: two stamps per wave, s_memtime
+    and the constant 100 MHz s_memrealtime; tools/_build/lib_clock).  Outside the timed region, never the product library."""
+    tool = os.path.join(ROOT, "tools", "kernel_clock.py")
+    lib = os.path.join(ROOT, "tools", "_build", "lib_clock", "libcpmpc.so")
+    if not os.path.exists(lib):
+        return {"error": "tools/_build/lib_clock/libcpmpc.so is not built (python tools/kernel_clock.py --build-only)"}
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "CPMPC_LIB")}
+    r = subprocess.run([sys.executable, tool, "--seconds", "1.5", "--batch", str(B)], env=env, capture_output=True,
+                       text=True, timeout=timeout)
+    recs = {}
+    for ln in r.stdout.splitlines():
+        ln = ln.strip()
+        if ln.startswith("{"):
+            try:
+                d = json.loads(ln)
+                recs[d["dtype"]] = d
+            except ValueError:
+                pass
+    if not recs:
+        return {"error": "kernel_clock.py gave no record (rc %d): %s" % (r.returncode, r.stderr[-300:])}
+    return recs
+
+
+def issue_of(clock_rec, dtype, B):
+    """Cycles per vector instruction per SIMD and the fraction of the issue ceiling, from the clock leg's cycles per
+    wave and the dynamic instruction mix of the last committed profile (profiles/traffic_latest*.json)."""
+    if not clock_rec or "cycles_per_wave_mean" not in clock_rec:
+        return None
+    out = {"clock_GHz_measured": round(clock_rec["clock_GHz"], 4),
+           "cycles_per_wave_mean": round(clock_rec["cycles_per_wave_mean"], 1),
+           "us_per_wave_mean": round(clock_rec["us_per_wave_mean"], 2),
+           "waves_per_simd": 2 if dtype == "f32" else 1,
+           "ms_per_step_of_the_diagnostic_build": round(clock_rec["ms_per_step"], 4)}
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json" if dtype == "f32" else "traffic_latest_%s.json" % dtype)
+    try:
+        tj = json.load(open(tpath))
+        mix = tj.get("instruction_mix_per_wave", {}).get("fused_sqp_kernel")
+        if mix and tj.get("batch") == B and mix.get("valu", 0) > 0:
+            floor = sum(ISSUE_CYCLES[k] * mix.get(k, 0.0) for k in ISSUE_CYCLES)
+            per_simd = clock_rec["cycles_per_wave_mean"] / out["waves_per_simd"]
+            out.update({"valu_instructions_per_wave": round(mix["valu"], 1),
+                        "cycles_per_valu_instruction_per_simd": round(per_simd / mix["valu"], 3),
+                        "issue_floor_cycles_per_wave": round(floor, 1),
+                        "issue_frac": round(floor / per_simd, 4),
+                        "mix_source": tj.get("source"),
+                        "note": "issue_frac = sum over instruction classes of (dynamic count per wave x full-rate issue "
+                                "cycles: 2 for 32-bit, 4 for fp64 arithmetic, 8 / 16 for f32 / f64 transcendentals) / (mean "
+                                "cycles a wave is resident / waves per SIMD)"})
+    except Exception:  # noqa: BLE001
+        pass
+    return out
+
+
 def variants(torch, pkg, args, tdt, dev, local_rank, x0, B):
     """Secondary measurements of SURVEY.md 8(d), outside the timed region and never `value`:
     (1) the same cold-start re-plan with the reference's exit tolerances enabled (optimization.hpp:30-34:
@@ -623,7 +684,7 @@ def run_rank(args):
         except Exception as exc:  # noqa: BLE001
             line["as_rank"]["parity"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     if as_rank:   # the secondary legs belong to the headline run
-        args.no_fp64 = args.no_variants = args.no_cpu_baseline = True
+        args.no_fp64 = args.no_variants = args.no_cpu_baseline = args.no_clock = True
     if world == 1 and args.dtype == "f32" and not args.no_fp64:
         try:
             opt64 = pkg.BatchOptimization(params, max_batch=B, dtype=torch.float64, device=local_rank)
@@ -643,6 +704,20 @@ def run_rank(args):
             del opt64, x64, outs64, o64
         except Exception as exc:  # noqa: BLE001
             line["fp64"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    if world == 1 and not args.no_clock and not as_rank and args.pipeline != "split":
+        # the clock the part holds under this kernel and what that makes of the issue ceiling
+        try:
+            recs = clock_leg(B)
+            if "error" in recs:
+                line["roofline"]["issue"] = recs
+            else:
+                line["roofline"]["issue"] = issue_of(recs.get(args.dtype), args.dtype, B)
+                line["roofline"]["clock_GHz_measured"] = (line["roofline"]["issue"] or {}).get("clock_GHz_measured")
+                if isinstance(line.get("fp64"), dict) and "roofline" in line["fp64"] and "f64" in recs:
+                    line["fp64"]["roofline"]["issue"] = issue_of(recs["f64"], "f64", B)
+                    line["fp64"]["roofline"]["clock_GHz_measured"] = recs["f64"]["clock_GHz"]
+        except Exception as exc:  # noqa: BLE001
+            line["roofline"]["issue"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     if world == 1 and not args.no_variants:
         try:
             line["variants"] = variants(torch, pkg, args, tdt, dev, local_rank, x0, B)
@@ -701,6 +776,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-fp64", action="store_true", help="skip the fp64 record")
     ap.add_argument("--no-variants", action="store_true", help="skip the secondary measurements (SURVEY 8d)")
+    ap.add_argument("--no-clock", action="store_true", help="skip the shader-clock / issue-ceiling leg")
     ap.add_argument("--pipeline", choices=["auto", "split", "fused"], default="auto")
     ap.add_argument("--as-rank", type=int, default=None, help="with --of W: solve rank R's shard of the W-GPU global "
                     "batch alone on this GPU (no process group)")

@@ -34,7 +34,9 @@ constexpr int kTermMaxLambda = 7;
 constexpr int kTermNonFinite = 8;
 
 // per-problem real scalars kept in the workspace (index into `sc`)
-enum { SC_LAMBDA = 0, SC_MU, SC_F_LAST, SC_CN_LAST, SC_UPREV, SC_ALPHA, SC_COUNT };
+// SC_TRIAL: 1 when SC_F_LAST / SC_CN_LAST are the merit pieces of the CURRENT iterate as the line search evaluated
+// them (the accepted trial point IS the new iterate, bit for bit), 0 when no trial has been accepted yet
+enum { SC_LAMBDA = 0, SC_MU, SC_F_LAST, SC_CN_LAST, SC_UPREV, SC_ALPHA, SC_TRIAL, SC_COUNT };
 // per-problem int scalars (index into `ist`)
 enum { IS_STATUS = 0, IS_ITERS, IS_LS_EVALS, IS_FAILED, IS_COUNT };
 
@@ -263,6 +265,7 @@ __global__ __launch_bounds__(256) void prepare_kernel(const SolverArgs<R, M> a) 
   a.sc[SC_F_LAST * st + p] = R(0);
   a.sc[SC_CN_LAST * st + p] = R(0);
   a.sc[SC_ALPHA * st + p] = R(1);
+  a.sc[SC_TRIAL * st + p] = R(0);
   a.ist[IS_STATUS * st + p] = kTermNone;
   a.ist[IS_ITERS * st + p] = 0;
   a.ist[IS_LS_EVALS * st + p] = 0;
@@ -886,6 +889,19 @@ __global__ CPMPC_QPLS_BOUNDS void qp_ls_kernel(const SolverArgs<R, M> a) {
   }
   if (status == kTermNone && (!Math<R>::finite(gd) || !Math<R>::finite(curv))) status = kTermQpIndefinite;
 
+  // ---- the merit at the iterate, evaluated the way the trials are --------------------------------------------
+  // f and cn above come out of the linearisation (RK4 with sensitivities, sums in sweep order); the line search
+  // evaluates its trial points with the Jacobian-free rollout in another order of operations.  Both are correct to
+  // rounding, but comparing phi(trial) from one path against phi(iterate) from the other puts a path-to-path rounding
+  // difference (~1e-13 relative, ~1e-10 absolute at f ~ 1e3) into every Armijo test, and the iteration stalls once
+  // the achievable decrease falls below it (measured: 1-2e-5 from the optimum in u against 5e-7 for the oracle, which
+  // evaluates both sides with one function).  The iterate IS the last accepted trial point, bit for bit, so its merit
+  // pieces as the line search computed them are at hand: use those.
+  const bool have_trial = a.sc[SC_TRIAL * st + p] != R(0);
+  if (have_trial) {
+    f = a.sc[SC_F_LAST * st + p];
+    cn = a.sc[SC_CN_LAST * st + p];
+  }
   // ---- penalty update (Nocedal & Wright 18.36, sigma = 1), merit slope --------------------------
   if (cn > R(0)) {
     const R mu_req = (gd + R(0.5) * curv) / ((R(1) - a.rho) * cn);
@@ -958,8 +974,9 @@ __global__ CPMPC_QPLS_BOUNDS void qp_ls_kernel(const SolverArgs<R, M> a) {
   if (status != kTermNonFinite) a.ist[IS_ITERS * st + p] += 1;
   a.sc[SC_LAMBDA * st + p] = lam;
   a.sc[SC_MU * st + p] = mu;
-  a.sc[SC_F_LAST * st + p] = f_t;
+  a.sc[SC_F_LAST * st + p] = f_t;   // accepted: the trial's pieces; else f, cn as used above (unchanged iterate)
   a.sc[SC_CN_LAST * st + p] = cn_t;
+  if (accepted && status != kTermNonFinite) a.sc[SC_TRIAL * st + p] = R(1);
   a.sc[SC_ALPHA * st + p] = a_start;
   a.ist[IS_STATUS * st + p] = status;
   a.ist[IS_LS_EVALS * st + p] += evals;

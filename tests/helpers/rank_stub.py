@@ -17,6 +17,12 @@ import bench  # noqa: E402
 
 args = bench.parse_args(sys.argv[1:])
 world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+if os.environ.get("CPMPC_STUB_FAIL_RANK") is not None:   # a rank that dies early while the others would wait for it
+    if rank == int(os.environ["CPMPC_STUB_FAIL_RANK"]):
+        sys.exit(3)
+    import time
+    time.sleep(120)
+    sys.exit(0)
 assert world == args.gpus and os.environ["CPMPC_BENCH_SPAWNED"] == "1"
 dist.init_process_group("gloo", rank=rank, world_size=world)
 sharding = importlib.import_module("cart-pole-mpc_amd.sharding")
@@ -29,11 +35,12 @@ g.wait_slot(slot)
 locals_ = [None] * world
 dist.all_gather_object(locals_, int(os.environ["LOCAL_RANK"]))
 t = sharding.max_over_ranks(float(rank), "cpu")
+per_rank = sharding.all_ranks([float(rank), 10.0 * rank], "cpu")
 if rank == 0:
     full = g.assembled(slot).numpy()
     print("noise before the line")
     print(json.dumps({"n_gpus": world, "world_size_seen": dist.get_world_size(), "gathered": list(full.shape),
                       "in_global_order": bool(np.array_equal(full, bench.synth_states(bench.SEED, total))),
-                      "local_ranks": locals_, "max_rank": t}))
+                      "local_ranks": locals_, "max_rank": t, "per_rank": per_rank}))
 dist.barrier()
 dist.destroy_process_group()

@@ -428,12 +428,10 @@ def test_warm_start_closed_loop(pkg, orc):
     for b in range(B):
         o_sim[b].set_state(x0[:, b])
     assert not opt.has_previous_solution()
-    # A lane is compared while the oracle solves it in a well-conditioned regime.  When a line search
-    # fails outright or the l1 penalty explodes (states far from anything trackable, e.g. the pole
-    # falling at 20 rad/s into a bumper), Armijo decisions are made at rounding-noise level and the two
-    # implementations may legitimately part ways; such a lane is dropped from then on.
-    tracked = np.ones(B, bool)
-    worst, compared = 0.0, 0
+    # Every lane at every tick (round 3: re-measured after round 2's fixes of the normal-equations conditioning and of
+    # the diverged-trial rule -- 0 of the 64 x 25 re-plans differ by more than 1e-6 or in their termination state, so
+    # nothing is dropped any more).
+    worst = 0.0
     for t in range(ticks):
         out = opt.step(sim.get_state().clone(), DYN_TEST, 0.0)
         u0 = out.u[0].contiguous()
@@ -442,18 +440,13 @@ def test_warm_start_closed_loop(pkg, orc):
         for b in range(B):
             o = o_opt[b].step(o_sim[b].get_state(), DYN_TEST, 0.0)
             o_sim[b].step(DYN_TEST, 0.01, o.u[0])
-            so = o.solver_outputs
-            if so.failed_steps > 0 or so.final_penalty > 1e6:
-                tracked[b] = False
-            if tracked[b]:
-                assert st_gpu[b] == so.termination_state, (t, b)
-                worst = max(worst, np.abs(u_gpu[:, b] - o.u).max())
-                compared += 1
+            assert st_gpu[b] == o.solver_outputs.termination_state, (t, b)
+            worst = max(worst, np.abs(u_gpu[:, b] - o.u).max())
     assert opt.has_previous_solution()
-    assert tracked.mean() >= 0.75 and compared >= 0.75 * B * ticks
+    print("warm-start closed loop, 64 controllers x 25 ticks: worst |du| %.2e" % worst)
     assert worst < 1e-5
     state = N_(sim.get_state())
-    for b in np.nonzero(tracked)[0]:
+    for b in range(B):
         np.testing.assert_allclose(state[:, b], o_sim[b].get_state(), rtol=0, atol=1e-6)
 
 
@@ -537,13 +530,16 @@ def test_full_size_properties_fp32(pkg, orc):
         d[1] = torch.remainder(d[1] + np.pi, 2 * np.pi) - np.pi
         assert (d.abs() <= 2e-5 * (1.0 + x.abs())).all(), k
         x = pred[k, :, :8192].contiguous()
-    # fp32 against the fp64 oracle on a sample: report, bound loosely (the reference is fp64-only)
-    samp = np.arange(0, B, B // 256)[:256]
+    # fp32 against the fp64 oracle on a sample of 2048 lanes (the reference is fp64-only: this is the price of single
+    # precision through five SQP iterations on unconverged problems, not a parity claim).  Measured: median 2.9e-4,
+    # 90.6 % of the lanes within 1e-2 (92.3 % over the whole batch, bench.py parity_sample).
+    samp = np.arange(0, B, B // 2048)[:2048]
     u_cpu, _, _, _, _ = orc.step_batch_cold(orc.default_opt_params(**NO_TOL), DYN_UI, 0.0, x0[:, samp])
     err = np.abs(N_(u[:, T(samp, torch.long)]) - u_cpu).max(axis=0)
-    print("fp32 vs fp64 oracle on 256 lanes: |du| median %.2e p90 %.2e max %.2e" % (
-        np.median(err), np.quantile(err, 0.9), err.max()))
-    assert np.median(err) < 5e-2
+    print("fp32 vs fp64 oracle on 2048 lanes: |du| median %.2e p90 %.2e within 1e-2: %.3f" % (
+        np.median(err), np.quantile(err, 0.9), (err < 1e-2).mean()))
+    assert np.median(err) < 2e-3
+    assert (err < 1e-2).mean() >= 0.88
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.float64, 1e-6)])
@@ -584,6 +580,35 @@ def test_full_size_fp64_every_lane(pkg, orc):
     print("full batch fp64: |du| max %.2e p99 %.2e median %.2e" % (err.max(), np.quantile(err, 0.99), np.median(err)))
     assert (N_(out.status) == st_cpu).all() and (N_(out.iterations) == it_cpu).all()
     assert err.max() < 1e-5, np.sort(err)[-5:]
+
+
+def test_reference_defaults_full_batch_exits_enabled(pkg, orc):
+    """The reference's own defaults (optimization.hpp:12-48: 8 iterations, relative_exit_tol 1e-5,
+    absolute_first_derivative_tol 1e-6) on the benchmark's 262 144 problems: termination state and iteration count agree
+    with the oracle on every lane, and every lane is within 1e-5 -- a lane that is not is handed to the extended-precision
+    build of the oracle, and the GPU must then be the closer of the two to it (round 2's sweep found one such lane at
+    1.3e-5, where the double oracle had moved 1.0e-5 and the GPU 3.2e-6)."""
+    import os
+    import bench
+    B = 262144
+    x0 = bench.synth_states(bench.SEED, B)
+    opt = pkg.BatchOptimization(pkg.default_params(), max_batch=B, dtype=torch.float64, device=0)
+    out = opt.step(T(x0), DYN_UI, 0.0)
+    threads = min(len(os.sched_getaffinity(0)), 16)
+    u_cpu, _, st_cpu, it_cpu, _ = orc.step_batch_cold(orc.default_opt_params(), DYN_UI, 0.0, x0, num_threads=threads)
+    u_gpu = N_(out.u)
+    err = np.abs(u_gpu - u_cpu).max(axis=0)
+    assert (N_(out.status) == st_cpu).all() and (N_(out.iterations) == it_cpu).all()
+    over = np.nonzero(err > 1e-5)[0]
+    print("reference defaults, exits on, B = 262144: |du| max %.2e p99 %.2e; lanes over 1e-5: %d" % (
+        err.max(), np.quantile(err, 0.99), over.size))
+    assert over.size <= 4, over.size
+    if over.size:
+        u_ld, _, _, _, _ = orc.step_batch_cold_ld(orc.default_opt_params(), DYN_UI, 0.0, x0[:, over])
+        e_gpu = np.abs(u_gpu[:, over] - u_ld).max(axis=0)
+        e_cpu = np.abs(u_cpu[:, over] - u_ld).max(axis=0)
+        print("  arbiter (extended precision): GPU %s, oracle %s" % (e_gpu, e_cpu))
+        assert (e_gpu < 1e-5).all() and (e_gpu <= e_cpu).all(), (over, e_gpu, e_cpu)
 
 
 def test_profiling_counts_launches(pkg):

@@ -228,15 +228,13 @@ def _lane_history(pkg, orc, over, dyn, sp, x0_lane, kmax):
     return hist
 
 
-def test_dropped_lanes_depart_at_a_decision_or_unconverged(pkg, orc):
-    """The fuzz and configuration tests accept that a few percent of lanes differ from the oracle by more than 1e-5
-    (test_gpu_parity.py).  This test takes every such lane of the fuzz cases and localises where it departs: both
-    implementations are re-run with max_iterations = 1, 2, ... and compared after each count.  Every dropped lane must
-    (a) agree (<= 1e-6, decisions identical) up to the iteration before it departs, and (b) depart either at an
-    iteration where the two make a different discrete decision (line-search trial count, exit test) or while its
-    shooting defects are still open (|c|_1 > 1e-4: the expansive regime), never silently on a converged problem."""
+def test_no_lane_of_the_fuzz_cases_is_dropped(pkg, orc):
+    """Round 1 tolerated a few percent of the fuzz lanes beyond 1e-5 and round 2 localised where each departed; since
+    round 2's two fixes none does.  This test pins that: over the 32 fuzz configurations every lane agrees with the
+    oracle in control sequence (1e-5), termination state and iteration count -- and should one ever reappear, its
+    history (agreement iteration by iteration up to the departure) is printed for the failure message."""
     from test_gpu_parity import _random_case
-    dropped = flips = unconverged = 0
+    dropped = []
     for seed in range(32):
         rng = np.random.default_rng(1000 + seed)
         over, dyn, sp = _random_case(rng)
@@ -248,20 +246,10 @@ def test_dropped_lanes_depart_at_a_decision_or_unconverged(pkg, orc):
         u_cpu, _, st_cpu, it_cpu, _ = orc.step_batch_cold(orc.default_opt_params(**over), dyn, sp, x0)
         err = np.abs(N_(out.u) - u_cpu).max(axis=0)
         bad = np.nonzero((err > 1e-5) | (N_(out.status) != st_cpu) | (N_(out.iterations) != it_cpu))[0]
-        for b in bad[:6]:
-            dropped += 1
-            hist = _lane_history(pkg, orc, over, dyn, sp, x0[:, b], int(over["max_iterations"]))
-            first = next(i for i, h in enumerate(hist) if h[0] > 1e-5 or h[1] != h[2])
-            for h in hist[:first]:                      # (a) agreement before the departure
-                assert h[0] <= 1e-6 and h[1] == h[2], (seed, b, hist)
-            e, gd, cd, cl1 = hist[first]
-            eq_before = hist[first - 1][3] if first > 0 else np.inf   # |c|_1 entering the departing iteration
-            if gd != cd:
-                flips += 1
-            else:
-                unconverged += 1
-                assert eq_before > 1e-4, (seed, b, hist)   # (b) same decisions, yet apart: only while far from feasible
-    print("dropped lanes over 32 fuzz cases: %d  (decision flips %d, expansive/unconverged %d)" % (dropped, flips, unconverged))
+        for b in bad[:2]:
+            dropped.append((seed, int(b), float(err[b]),
+                            _lane_history(pkg, orc, over, dyn, sp, x0[:, b], int(over["max_iterations"]))))
+    assert not dropped, dropped
 
 
 # ------------------------------------------------------------------------------------------------

@@ -40,7 +40,7 @@ def test_rccl_branch_in_a_world_of_one():
     tensors, barrier, max-reduce of the time, per-rank all-gather -- executed in a world of one
     (CPMPC_BENCH_FORCE_DIST=1), so that RCCL code does not run for the first time in the driver's scaling run."""
     line = _bench(["--gpus", "1", "--batch", "8192", "--steps", "3", "--warmup", "1", "--no-fp64", "--no-variants",
-                   "--no-cpu-baseline"], {"CPMPC_BENCH_FORCE_DIST": "1", "MASTER_PORT": "29533"})
+                   "--no-cpu-baseline", "--no-clock"], {"CPMPC_BENCH_FORCE_DIST": "1", "MASTER_PORT": "29533"})
     d = line["distributed"]
     assert d["backend"] == "nccl" and d["world_size_seen"] == 1
     assert line["gathered"]["shape"] == [40, 8192] and line["gathered"]["own_block_intact"]

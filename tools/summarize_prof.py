@@ -70,7 +70,7 @@ def main():
                     stats[k] = {"calls": int(row[1]), "avg_ns": float(row[3]), "pct": float(row[4])}
     # counters
     counters = defaultdict(dict)
-    for sub in ("fetch", "write", "sq", "sq2"):
+    for sub in ("fetch", "write", "sq", "sq2", "mix1", "mix2"):
         for path in glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")):
             for k, cs in read_counters(path).items():
                 for c, vals in cs.items():
@@ -109,12 +109,31 @@ def main():
                 "wait_any_over_wave_cycles": cs.get("SQ_WAIT_ANY", 0) / cs["SQ_WAVE_CYCLES"],
                 "valu_insts_per_wave": cs.get("SQ_INSTS_VALU", 0) / max(cs.get("SQ_WAVES", 1), 1),
             }
+    # dynamic vector-instruction mix per wave (the mix1 / mix2 passes of prof.sh), by issue-cost class
+    mix = {}
+    for k, cs in counters.items():
+        waves = cs.get("SQ_WAVES", 0)
+        if waves <= 0 or "SQ_INSTS_VALU" not in cs:
+            continue
+        g = lambda name: cs.get(name, 0.0) / waves   # noqa: E731
+        m = {"valu": g("SQ_INSTS_VALU"),
+             "f32_arith": g("SQ_INSTS_VALU_ADD_F32") + g("SQ_INSTS_VALU_MUL_F32") + g("SQ_INSTS_VALU_FMA_F32"),
+             "f32_trans": g("SQ_INSTS_VALU_TRANS_F32"),
+             "f64_arith": g("SQ_INSTS_VALU_ADD_F64") + g("SQ_INSTS_VALU_MUL_F64") + g("SQ_INSTS_VALU_FMA_F64"),
+             "f64_trans": g("SQ_INSTS_VALU_TRANS_F64"),
+             "int32": g("SQ_INSTS_VALU_INT32"), "int64": g("SQ_INSTS_VALU_INT64"), "cvt": g("SQ_INSTS_VALU_CVT"),
+             "salu": g("SQ_INSTS_SALU"), "lds": g("SQ_INSTS_LDS")}
+        m["other_32bit"] = max(0.0, m["valu"] - m["f32_arith"] - m["f32_trans"] - m["f64_arith"] - m["f64_trans"])
+        mix[k] = m
+    if mix:
+        summary["instruction_mix_per_wave"] = mix
     with open(os.path.join(out_dir, tag + "_pmc_summary.json"), "w") as fh:
         json.dump(summary, fh, indent=1, sort_keys=True)
     if traffic and "--no-traffic" not in sys.argv:   # the headline workload only: bench.py reads this file
         tname = "traffic_latest.json" if dtype == "f32" else "traffic_latest_%s.json" % dtype
         with open(os.path.join(out_dir, tname), "w") as fh:
             json.dump({"tag": tag, "dtype": dtype, "batch": batch, "per_launch_bytes": traffic,
+                       "instruction_mix_per_wave": mix,
                        "source": "profiles/%s_pmc_summary.json" % tag}, fh, indent=1, sort_keys=True)
     print(json.dumps(summary, indent=1, sort_keys=True))
 
