@@ -80,6 +80,8 @@ struct Math<float> {
   static __device__ __forceinline__ float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
   static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 #endif
+  static constexpr bool kIncrementalTrig = false;  // v_sin_f32 / v_cos_f32 are cheaper than a rotation
+  static constexpr bool kMergedReciprocals = false;
   static __device__ __forceinline__ float div(float a, float b) { return a / b; }
   // |v| and 1/|v| (0 when |v| = 0: the hardware sqrt flushes a denormal argument to zero, see cartpole_accel)
   static __device__ __forceinline__ void sqrt_inv(float x, float& s, float& r) {
@@ -121,6 +123,47 @@ __device__ __forceinline__ double horner(double p, double z, double c) {
 #endif
 }
 
+#ifndef CPMPC_F64_IEEE_DIV
+#define CPMPC_F64_IEEE_DIV 0  // 1: compiler-expanded IEEE division and sqrt in the fp64 kernels (A/B of the Newton routines)
+#endif
+// The fp64 polynomial coefficients, read from constant memory instead of being immediates: as immediates every use costs
+// two s_mov_b32 in front of the v_fma_f64 that takes the pair (the kernel has no scalar registers to keep ~35 pairs
+// resident), and at ONE wave per SIMD -- where the fp64 fused kernel runs -- a scalar instruction takes an issue slot of
+// the wave like a vector one does (measured: 163 k instructions per wave x 4.75 cycles = the wave's residence time).
+// A scalar load brings up to eight coefficients in one instruction.  -DCPMPC_F64_COEF_TABLE=0 restores the immediates.
+#ifndef CPMPC_F64_COEF_TABLE
+#define CPMPC_F64_COEF_TABLE 1
+#endif
+#if CPMPC_F64_COEF_TABLE
+__constant__ double kCoef64[23] = {
+    2.75573137070700676789e-06,
+    -1.98412698298579493134e-04,
+    8.33333333332248946124e-03,
+    -1.66666666666666324348e-01,
+    -2.75573143513906633035e-07,
+    2.48015872894767294178e-05,
+    -1.38888888888741095749e-03,
+    4.16666666666666019037e-02,
+    2.08767569878680989792e-09,
+    2.50521083854417187751e-08,
+    2.75573192239858906526e-07,
+    2.75573192239858906526e-06,
+    2.48015873015873015873e-05,
+    1.98412698412698412698e-04,
+    1.38888888888888888889e-03,
+    8.33333333333333333333e-03,
+    4.16666666666666666667e-02,
+    1.66666666666666666667e-01,
+    0.5,
+    -1.98412698412698412698e-04,
+    -1.66666666666666666667e-01,
+    -1.38888888888888888889e-03,
+    -0.5,
+};
+#define CPMPC_C64(I, LITERAL) (kCoef64[I])
+#else
+#define CPMPC_C64(I, LITERAL) (LITERAL)
+#endif
 template <>
 struct Math<double> {
 #if CPMPC_F64_LIBM
@@ -135,17 +178,17 @@ struct Math<double> {
     const double z = r * r;
     // sin(r) = r + r z S(z)
     double sp = ::fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-    sp = horner(sp, z, 2.75573137070700676789e-06);
-    sp = horner(sp, z, -1.98412698298579493134e-04);
-    sp = horner(sp, z, 8.33333333332248946124e-03);
-    sp = horner(sp, z, -1.66666666666666324348e-01);
+    sp = horner(sp, z, CPMPC_C64(0, 2.75573137070700676789e-06));
+    sp = horner(sp, z, CPMPC_C64(1, -1.98412698298579493134e-04));
+    sp = horner(sp, z, CPMPC_C64(2, 8.33333333332248946124e-03));
+    sp = horner(sp, z, CPMPC_C64(3, -1.66666666666666324348e-01));
     const double sr = ::fma(r * z, sp, r);
     // cos(r) = w + ((1 - w) - z/2 + z z C(z)),  w = 1 - z/2
     double cp = ::fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-    cp = horner(cp, z, -2.75573143513906633035e-07);
-    cp = horner(cp, z, 2.48015872894767294178e-05);
-    cp = horner(cp, z, -1.38888888888741095749e-03);
-    cp = horner(cp, z, 4.16666666666666019037e-02);
+    cp = horner(cp, z, CPMPC_C64(4, -2.75573143513906633035e-07));
+    cp = horner(cp, z, CPMPC_C64(5, 2.48015872894767294178e-05));
+    cp = horner(cp, z, CPMPC_C64(6, -1.38888888888741095749e-03));
+    cp = horner(cp, z, CPMPC_C64(7, 4.16666666666666019037e-02));
     const double hz = 0.5 * z;
     const double w = 1.0 - hz;
     const double cr = w + (((1.0 - w) - hz) + z * z * cp);
@@ -170,27 +213,93 @@ struct Math<double> {
     r = ::fma(-nf, 1.90821492927058770002e-10, r);
     // expm1(r) = r + r^2 (1/2! + r (1/3! + ... + r / 13!)),  |r| <= ln2 / 2
     double p = 1.6059043836821613e-10;                       // 1/13!
-    p = horner(p, r, 2.08767569878680989792e-09);            // 1/12!
-    p = horner(p, r, 2.50521083854417187751e-08);            // 1/11!
-    p = horner(p, r, 2.75573192239858906526e-07);            // 1/10!
-    p = horner(p, r, 2.75573192239858906526e-06);            // 1/9!
-    p = horner(p, r, 2.48015873015873015873e-05);            // 1/8!
-    p = horner(p, r, 1.98412698412698412698e-04);            // 1/7!
-    p = horner(p, r, 1.38888888888888888889e-03);            // 1/6!
-    p = horner(p, r, 8.33333333333333333333e-03);            // 1/5!
-    p = horner(p, r, 4.16666666666666666667e-02);            // 1/4!
-    p = horner(p, r, 1.66666666666666666667e-01);            // 1/3!
-    p = horner(p, r, 0.5);                                   // 1/2!
+    p = horner(p, r, CPMPC_C64(8, 2.08767569878680989792e-09));            // 1/12!
+    p = horner(p, r, CPMPC_C64(9, 2.50521083854417187751e-08));            // 1/11!
+    p = horner(p, r, CPMPC_C64(10, 2.75573192239858906526e-07));            // 1/10!
+    p = horner(p, r, CPMPC_C64(11, 2.75573192239858906526e-06));            // 1/9!
+    p = horner(p, r, CPMPC_C64(12, 2.48015873015873015873e-05));            // 1/8!
+    p = horner(p, r, CPMPC_C64(13, 1.98412698412698412698e-04));            // 1/7!
+    p = horner(p, r, CPMPC_C64(14, 1.38888888888888888889e-03));            // 1/6!
+    p = horner(p, r, CPMPC_C64(15, 8.33333333333333333333e-03));            // 1/5!
+    p = horner(p, r, CPMPC_C64(16, 4.16666666666666666667e-02));            // 1/4!
+    p = horner(p, r, CPMPC_C64(17, 1.66666666666666666667e-01));            // 1/3!
+    p = horner(p, r, CPMPC_C64(18, 0.5));                                   // 1/2!
     p = ::fma(r * r, p, r);
     const double two_n = ::ldexp(1.0, (int)nf);              // n in [-116, 0]
     const double t = ::fma(two_n, p, two_n - 1.0);           // expm1(y) in (-1, 0]
     return ::copysign(div(-t, t + 2.0), x);
   }
+  // tanh(x) = sign(x) num / den with num = -expm1(-2|x|) >= 0, den = expm1(-2|x|) + 2 in (1, 2]: the quotient is left to
+  // the caller, who has another reciprocal to take at the same place and takes ONE of the product (cartpole_accel_sc)
+  // e2 = exp(-2|x|) comes along for the slope: sech^2 x = 4 e2 / den^2 has full relative accuracy where 1 - tanh^2
+  // cancels (a saturated friction term with a tiny v_mu multiplies that slope by up to 1e6).
+  static __device__ __forceinline__ void tanh_parts(double x, double& num, double& den, double& e2) {
+    double y = -2.0 * ::fabs(x);
+    y = (y < -80.0) ? -80.0 : y;
+    const double nf = ::rint(y * 1.44269504088896338700e+00);
+    double r = ::fma(-nf, 6.93147180369123816490e-01, y);
+    r = ::fma(-nf, 1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;
+    p = horner(p, r, CPMPC_C64(8, 2.08767569878680989792e-09));
+    p = horner(p, r, CPMPC_C64(9, 2.50521083854417187751e-08));
+    p = horner(p, r, CPMPC_C64(10, 2.75573192239858906526e-07));
+    p = horner(p, r, CPMPC_C64(11, 2.75573192239858906526e-06));
+    p = horner(p, r, CPMPC_C64(12, 2.48015873015873015873e-05));
+    p = horner(p, r, CPMPC_C64(13, 1.98412698412698412698e-04));
+    p = horner(p, r, CPMPC_C64(14, 1.38888888888888888889e-03));
+    p = horner(p, r, CPMPC_C64(15, 8.33333333333333333333e-03));
+    p = horner(p, r, CPMPC_C64(16, 4.16666666666666666667e-02));
+    p = horner(p, r, CPMPC_C64(17, 1.66666666666666666667e-01));
+    p = horner(p, r, CPMPC_C64(18, 0.5));
+    p = ::fma(r * r, p, r);
+    const double two_n = ::ldexp(1.0, (int)nf);
+    const double t = ::fma(two_n, p, two_n - 1.0);
+    num = -t;
+    den = t + 2.0;
+    e2 = ::fma(two_n, p, two_n);
+  }
+  // sin and cos of th0 + d from (s0, c0) = sincos(th0) by one rotation, for |d| <= 1: the Taylor kernels of sin and
+  // cos - 1 are evaluated at d/4 (|d/4| <= 1/4: exact to 3e-18 through d^11 / d^12) and doubled twice
+  // (sin 2a = 2 sin a (1 + (cos a - 1)), cos 2a - 1 = -2 sin^2 a: no cancellation), and the result is formed as
+  // s0 + (small), c0 + (small), so it carries the rounding of the base pair plus an ulp or two.  The stages of one RK4
+  // step evaluate the pole angle at th, th + (h/2) w1, th + (h/2) w2, th + h w3: |d| <= 1 covers poles up to 100 rad/s
+  // at the reference's step of 10 ms (measured on the benchmark distribution: 12 % of the steps exceed 25 rad/s, none
+  // 90) -- 26 vector instructions against ~45 for the argument reduction, both minimax kernels and the quadrant selects
+  // of a full sincos.
+  static __device__ __forceinline__ void sincos_delta(double s0, double c0, double d, double& s, double& c) {
+    const double q = 0.25 * d;
+    const double z = q * q;
+    double sp = ::fma(z, -2.50521083854417187751e-08, 2.75573192239858906526e-06);  // -1/11!, 1/9!
+    sp = horner(sp, z, CPMPC_C64(19, -1.98412698412698412698e-04));                                // -1/7!
+    sp = horner(sp, z, CPMPC_C64(15, 8.33333333333333333333e-03));                                 // 1/5!
+    sp = horner(sp, z, CPMPC_C64(20, -1.66666666666666666667e-01));                                // -1/3!
+    double sd = ::fma(q * z, sp, q);                                                // sin(d/4)
+    double cp = ::fma(z, 2.08767569878680989792e-09, -2.75573192239858906526e-07);  // 1/12!, -1/10!
+    cp = horner(cp, z, CPMPC_C64(12, 2.48015873015873015873e-05));                                 // 1/8!
+    cp = horner(cp, z, CPMPC_C64(21, -1.38888888888888888889e-03));                                // -1/6!
+    cp = horner(cp, z, CPMPC_C64(16, 4.16666666666666666667e-02));                                 // 1/4!
+    cp = horner(cp, z, CPMPC_C64(22, -0.5));                                                       // -1/2!
+    double cm1 = z * cp;                                                            // cos(d/4) - 1
+#pragma unroll
+    for (int dbl = 0; dbl < 2; ++dbl) {  // a -> 2a
+      const double t = sd + sd;
+      const double s2 = ::fma(t, cm1, t);
+      cm1 = -t * sd;
+      sd = s2;
+    }
+    s = s0 + ::fma(c0, sd, s0 * cm1);
+    c = c0 + ::fma(-s0, sd, c0 * cm1);
+  }
 #endif
+#ifndef CPMPC_F64_TRIG_ROTATE
+#define CPMPC_F64_TRIG_ROTATE 1  // 0: a full sincos at every RK4 stage (A/B of the rotation above)
+#endif
+#ifndef CPMPC_F64_MERGED_RCP
+#define CPMPC_F64_MERGED_RCP 1   // 0: tanh's quotient and 1/den by two separate Newton chains (A/B)
+#endif
+  static constexpr bool kIncrementalTrig = CPMPC_F64_TRIG_ROTATE && !CPMPC_F64_LIBM;
+  static constexpr bool kMergedReciprocals = CPMPC_F64_MERGED_RCP && !CPMPC_F64_LIBM && !CPMPC_F64_IEEE_DIV;
   static __device__ __forceinline__ double tanh_scaled(double x, double scale, double) { return tanh(x * scale); }
-#ifndef CPMPC_F64_IEEE_DIV
-#define CPMPC_F64_IEEE_DIV 0  // 1: compiler-expanded IEEE division and sqrt in the fp64 kernels (A/B of the routines below)
-#endif
 #if CPMPC_F64_LIBM || CPMPC_F64_IEEE_DIV
   static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
   static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
@@ -324,12 +433,11 @@ struct ExtForce {
 // only the two non-trivial rows are ever materialised.
 // ------------------------------------------------------------------------------------------------
 template <typename R, bool WITH_J, bool HAS_EXT>
-__device__ __forceinline__ void cartpole_accel(const CartPoleConsts<R>& k, const R bx, const R th,
-                                               const R v, const R w, const R u,
-                                               const ExtForce<R>& fe, R& a_x, R& a_th,
-                                               R (&Ja)[2][4], R (&Jua)[2]) {
-  R s, c;
-  Math<R>::sincos(th, s, c);
+__device__ __forceinline__ void cartpole_accel_sc(const CartPoleConsts<R>& k, const R bx, const R s, const R c,
+                                                  const R v, const R w, const R u,
+                                                  const ExtForce<R>& fe, R& a_x, R& a_th,
+                                                  R (&Ja)[2][4], R (&Jua)[2]) {
+  // (s, c) = sin, cos of the pole angle; the angle itself enters the equations of motion through them only
 
   // bumper springs (strict comparisons, as the generated branches)
   const R e_r = bx - k.xs;
@@ -338,8 +446,23 @@ __device__ __forceinline__ void cartpole_accel(const CartPoleConsts<R>& k, const
   const bool on_l = R(0) < e_l;
   const R F_s = k.ks * ((on_l ? e_l : R(0)) - (on_r ? e_r : R(0)));
 
-  // smoothed Coulomb friction
-  const R tv = Math<R>::tanh_scaled(v, k.inv_v_mu, k.tanh_k2);
+  // smoothed Coulomb friction, and 1 / (m_t - m_1 s^2).  Where a reciprocal is a Newton chain (fp64) the friction
+  // tanh = num / dt and 1 / den share ONE reciprocal, of the product: 1/den = r dt, tanh = num (r den)
+  const R den = k.mt - k.m_1 * s * s;
+  R tv, inv_den, sech2 = R(0);
+  if constexpr (Math<R>::kMergedReciprocals) {
+    R num, dt, e2;
+    Math<R>::tanh_parts(v * k.inv_v_mu, num, dt, e2);
+    const R r = Math<R>::rcp(den * dt);
+    inv_den = r * dt;
+    const R idt = r * den;
+    const R q = num * idt;
+    if (WITH_J) sech2 = R(4) * e2 * (idt * idt);
+    tv = (v < R(0)) ? -q : q;  // (a NaN speed gives a NaN quotient either way)
+  } else {
+    tv = Math<R>::tanh_scaled(v, k.inv_v_mu, k.tanh_k2);
+    inv_den = Math<R>::rcp(den);
+  }
   const R F_f = tv * k.fr;
 
   // air drag on the pole mass
@@ -361,8 +484,6 @@ __device__ __forceinline__ void cartpole_accel(const CartPoleConsts<R>& k, const
     F_th += k.L * (fe.fmy * c - fe.fmx * s);
   }
 
-  const R den = k.mt - k.m_1 * s * s;
-  const R inv_den = Math<R>::rcp(den);
   const R sl = s * k.inv_L;
   const R N_x = F_b + sl * F_th;
   const R N_th = sl * F_b + k.kap * F_th;
@@ -384,7 +505,7 @@ __device__ __forceinline__ void cartpole_accel(const CartPoleConsts<R>& k, const
     const R dDt0 = k.half_cd_L * (dn0 * e - n * (c * v));
     const R dDt1 = k.half_cd_L * (dn1 * e - n * s);
     const R dDt2 = k.half_cd_L * (dn2 * e + n * k.L);
-    const R dFf_dv = (R(1) - tv * tv) * k.fr_vmu;
+    const R dFf_dv = (Math<R>::kMergedReciprocals ? sech2 : (R(1) - tv * tv)) * k.fr_vmu;
     const R dFs_dbx = k.ks * ((on_l ? R(-1) : R(0)) - (on_r ? R(1) : R(0)));
 
     const R dFb0 = -dDx0 - k.m1L * w * w * s;
@@ -414,6 +535,46 @@ __device__ __forceinline__ void cartpole_accel(const CartPoleConsts<R>& k, const
     Ja[1][3] = dNt2 * inv_den;
     Jua[0] = inv_den;       // single_pendulum_dynamics.hpp:179-184
     Jua[1] = sl * inv_den;
+  }
+}
+
+template <typename R, bool WITH_J, bool HAS_EXT>
+__device__ __forceinline__ void cartpole_accel(const CartPoleConsts<R>& k, const R bx, const R th,
+                                               const R v, const R w, const R u,
+                                               const ExtForce<R>& fe, R& a_x, R& a_th,
+                                               R (&Ja)[2][4], R (&Jua)[2]) {
+  R s, c;
+  Math<R>::sincos(th, s, c);
+  cartpole_accel_sc<R, WITH_J, HAS_EXT>(k, bx, s, c, v, w, u, fe, a_x, a_th, Ja, Jua);
+}
+
+// The pole angle's sine and cosine across the four stages of one RK4 step: stage 1 evaluates them in full and keeps
+// the base; stages 2-4 are a rotation away (Math<R>::sincos_delta) unless some lane of the wave moves further than the
+// kernels cover (|d| > 1 rad within one step: a pole at more than 100 rad/s), which takes the full path for that lane.
+template <typename R>
+struct TrigBase {
+  R th0, s0, c0;
+};
+template <typename R, int STAGE>
+__device__ __forceinline__ void stage_sincos(TrigBase<R>& tb, const R th, R& s, R& c) {
+  if constexpr (Math<R>::kIncrementalTrig) {
+    if constexpr (STAGE == 1) {
+      Math<R>::sincos(th, s, c);
+      tb.th0 = th;
+      tb.s0 = s;
+      tb.c0 = c;
+    } else {
+      // per LANE, never per wave: a problem's arithmetic must not depend on what its neighbours in the wave do
+      // (batch-position independence: staged, sharded and stand-alone solves are bitwise equal).  The far branch also
+      // takes a NaN.
+      const R d = th - tb.th0;
+      Math<R>::sincos_delta(tb.s0, tb.c0, d, s, c);
+#ifndef CPMPC_F64_TRIG_NO_FALLBACK  // (defined only to count the main path's instructions in a listing)
+      if (__builtin_expect(!(Math<R>::fabs(d) <= R(1)), 0)) Math<R>::sincos(th, s, c);
+#endif
+    }
+  } else {
+    Math<R>::sincos(th, s, c);
   }
 }
 

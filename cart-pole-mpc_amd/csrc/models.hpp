@@ -40,8 +40,20 @@ struct SingleModelHandWritten {
                                                R (&Jua)[NQ]) {
     cartpole_accel<R, WITH_J, HAS_EXT>(k, x[0], x[1], x[2], x[3], u, fe, a[0], a[1], Ja, Jua);
   }
+  // the same at stage STAGE (1..4) of an RK4 step, with what the stages can share (the pole angle's sine and cosine)
+  using StepCache = TrigBase<R>;
+  template <bool WITH_J, bool HAS_EXT, int STAGE>
+  __device__ __forceinline__ static void accel_stage(const Consts& k, const R (&x)[NX], const R u,
+                                                     const ExtForce<R>& fe, R (&a)[NQ], R (&Ja)[NQ][NX],
+                                                     R (&Jua)[NQ], StepCache& sc) {
+    R s, c;
+    stage_sincos<R, STAGE>(sc, x[1], s, c);
+    cartpole_accel_sc<R, WITH_J, HAS_EXT>(k, x[0], s, c, x[2], x[3], u, fe, a[0], a[1], Ja, Jua);
+  }
 };
 
+// models without anything to share between the stages of a step
+struct NoStepCache {};
 // the same model on the generated code (README.md:60-71 "Changing the dynamics": edit the Lagrangian in
 // tools/gen_dynamics.py, run it, rebuild with -DCPMPC_GENERATED_SINGLE=1)
 template <typename R>
@@ -60,6 +72,13 @@ struct SingleModelGenerated {
       single_pendulum_gen_accel_ext<R, WITH_J>(k, x[0], x[1], x[2], x[3], u, fe.fbx, fe.fmx, fe.fmy, a, Ja, Jua);
     else
       single_pendulum_gen_accel_noext<R, WITH_J>(k, x[0], x[1], x[2], x[3], u, R(0), R(0), R(0), a, Ja, Jua);
+  }
+  using StepCache = NoStepCache;
+  template <bool WITH_J, bool HAS_EXT, int STAGE>
+  __device__ __forceinline__ static void accel_stage(const Consts& k, const R (&x)[NX], const R u,
+                                                     const ExtForce<R>& fe, R (&a)[NQ], R (&Ja)[NQ][NX],
+                                                     R (&Jua)[NQ], StepCache&) {
+    accel<WITH_J, HAS_EXT>(k, x, u, fe, a, Ja, Jua);
   }
 };
 
@@ -139,6 +158,13 @@ struct DoubleModel {
       solve(L, id, R(1), R(0), R(0), Jua);
     }
   }
+  using StepCache = NoStepCache;
+  template <bool WITH_J, bool HAS_EXT, int STAGE>
+  __device__ __forceinline__ static void accel_stage(const Consts& k, const R (&x)[NX], const R u,
+                                                     const ExtForce<R>& fe, R (&a)[NQ], R (&Ja)[NQ][NX],
+                                                     R (&Jua)[NQ], StepCache&) {
+    accel<WITH_J, HAS_EXT>(k, x, u, fe, a, Ja, Jua);
+  }
 };
 
 // pole angles are components 1..NQ-1 (wrapped to (-pi, pi]); component 0 is the base position (clamped)
@@ -157,28 +183,29 @@ __device__ __forceinline__ void rk4_step_m(const typename M::Consts& k, const R 
   R Ja[NQ][NX], Jua[NQ];
   R a1[NQ], a2[NQ], a3[NQ], a4[NQ], v2[NQ], v3[NQ], v4[NQ], xt[NX];
   const R hh = h / R(2);
-  M::template accel<false, HAS_EXT>(k, x, u, fe, a1, Ja, Jua);  // k1 = [x_v; a1]
+  typename M::StepCache sc;
+  M::template accel_stage<false, HAS_EXT, 1>(k, x, u, fe, a1, Ja, Jua, sc);  // k1 = [x_v; a1]
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
     v2[i] = x[NQ + i] + a1[i] * hh;
     xt[i] = x[i] + x[NQ + i] * hh;
     xt[NQ + i] = v2[i];
   }
-  M::template accel<false, HAS_EXT>(k, xt, u, fe, a2, Ja, Jua);  // k2 = [v2; a2]
+  M::template accel_stage<false, HAS_EXT, 2>(k, xt, u, fe, a2, Ja, Jua, sc);  // k2 = [v2; a2]
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
     v3[i] = x[NQ + i] + a2[i] * hh;
     xt[i] = x[i] + v2[i] * hh;
     xt[NQ + i] = v3[i];
   }
-  M::template accel<false, HAS_EXT>(k, xt, u, fe, a3, Ja, Jua);  // k3 = [v3; a3]
+  M::template accel_stage<false, HAS_EXT, 3>(k, xt, u, fe, a3, Ja, Jua, sc);  // k3 = [v3; a3]
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
     v4[i] = x[NQ + i] + a3[i] * h;
     xt[i] = x[i] + v3[i] * h;
     xt[NQ + i] = v4[i];
   }
-  M::template accel<false, HAS_EXT>(k, xt, u, fe, a4, Ja, Jua);  // k4 = [v4; a4]
+  M::template accel_stage<false, HAS_EXT, 4>(k, xt, u, fe, a4, Ja, Jua, sc);  // k4 = [v4; a4]
   const R h6 = h / R(6);
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
@@ -232,7 +259,8 @@ __device__ __forceinline__ void rk4_step_jac_m(const typename M::Consts& k, cons
   R a1[NQ], a2[NQ], a3[NQ], a4[NQ], v2[NQ], v3[NQ], v4[NQ], xt[NX];
 
   // stage 1
-  M::template accel<true, HAS_EXT>(k, x, u, fe, a1, Ja, Jua);
+  typename M::StepCache sc;
+  M::template accel_stage<true, HAS_EXT, 1>(k, x, u, fe, a1, Ja, Jua, sc);
 #pragma unroll
   for (int r = 0; r < NQ; ++r) {
 #pragma unroll
@@ -257,7 +285,7 @@ __device__ __forceinline__ void rk4_step_jac_m(const typename M::Consts& k, cons
     xt[i] = x[i] + x[NQ + i] * hh;
     xt[NQ + i] = v2[i];
   }
-  M::template accel<true, HAS_EXT>(k, xt, u, fe, a2, Ja, Jua);
+  M::template accel_stage<true, HAS_EXT, 2>(k, xt, u, fe, a2, Ja, Jua, sc);
   stage_chain_m<R, NX, NQ>(Ja, Jua, hh, D, d, Dn, dn);
 #pragma unroll
   for (int r = 0; r < NX; ++r) {
@@ -277,7 +305,7 @@ __device__ __forceinline__ void rk4_step_jac_m(const typename M::Consts& k, cons
     xt[i] = x[i] + v2[i] * hh;
     xt[NQ + i] = v3[i];
   }
-  M::template accel<true, HAS_EXT>(k, xt, u, fe, a3, Ja, Jua);
+  M::template accel_stage<true, HAS_EXT, 3>(k, xt, u, fe, a3, Ja, Jua, sc);
   stage_chain_m<R, NX, NQ>(Ja, Jua, hh, D, d, Dn, dn);
 #pragma unroll
   for (int r = 0; r < NX; ++r) {
@@ -297,7 +325,7 @@ __device__ __forceinline__ void rk4_step_jac_m(const typename M::Consts& k, cons
     xt[i] = x[i] + v3[i] * h;
     xt[NQ + i] = v4[i];
   }
-  M::template accel<true, HAS_EXT>(k, xt, u, fe, a4, Ja, Jua);
+  M::template accel_stage<true, HAS_EXT, 4>(k, xt, u, fe, a4, Ja, Jua, sc);
   stage_chain_m<R, NX, NQ>(Ja, Jua, h, D, d, Dn, dn);
 
   const R h6 = h / R(6);

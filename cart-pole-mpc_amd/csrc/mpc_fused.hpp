@@ -151,6 +151,9 @@ __device__ __forceinline__ R group_last(R v, int gbase) {
 #ifndef CPMPC_SWEEP_UNROLL
 #define CPMPC_SWEEP_UNROLL 5
 #endif
+#ifndef CPMPC_FUSED_EXTRA_ATTR
+#define CPMPC_FUSED_EXTRA_ATTR  // experiments: e.g. -DCPMPC_FUSED_EXTRA_ATTR='__attribute__((amdgpu_num_vgpr(168)))'
+#endif
 #define CPMPC_FUSED_BOUNDS __launch_bounds__(64, ((sizeof(R) == 4 && M::NX <= 4) ? CPMPC_FUSED_WAVES_F32 : 1))
 
 // Debug build only (-DCPMPC_FUSED_TIMING): shader-clock cycles per phase, summed over waves, read back by
@@ -201,19 +204,64 @@ __device__ unsigned long long g_fused_clock[4];  // sum of shader cycles, sum of
 #define CPMPC_CLOCK_END() do { } while (0)
 #endif
 
+// Lean LDS layout, an experiment kept as a build option (round 3, measured negative, default off).  Motivation
+// (tools/ubench/clock.hip): ONE wave issues a vector instruction every ~5.1 cycles at best, so the two waves per SIMD the
+// fp32 kernel runs keep a 2-cycle issue port 39 % busy and a third would saturate it.  Three waves need <= 168 registers
+// (costs this kernel 24 spilled values, none inside a loop) and less LDS: with (U^-1 g)_k sharing the slot of du_k (the
+// previous step is dead when sweep 1 writes it; sweep 1b turns it into v_k in place) a wave needs 17.5 KB instead of 20
+// and nine fit a CU instead of eight (-DCPMPC_FUSED_LEAN_LDS=1): measured 108.4 M re-plans/s against 116.3 M; with the
+// 1/d_k of a lane's controls in registers as well (15 KB, ten waves per CU, -DCPMPC_FUSED_ID_REGS=1) the fully unrolled
+// sweeps spill 109-151 values: 99.0 M.  A third wave on one or two of a CU's four SIMDs does not pay for the registers
+// it takes from the other two.
+#ifndef CPMPC_FUSED_LEAN_LDS
+#define CPMPC_FUSED_LEAN_LDS 0
+#endif
+template <typename R, typename M, int SP>
+__host__ __device__ constexpr bool fused_lean() {
+  return CPMPC_FUSED_LEAN_LDS && sizeof(R) == 4 && M::NX <= 4 && SP <= 10;
+}
+#undef CPMPC_FUSED_BOUNDS
+#define CPMPC_FUSED_BOUNDS_S __launch_bounds__(64, (fused_lean<R, M, SP>() ? 3 : ((sizeof(R) == 4 && M::NX <= 4) ? CPMPC_FUSED_WAVES_F32 : 1)))
+#define CPMPC_FUSED_BOUNDS __launch_bounds__(64, ((sizeof(R) == 4 && M::NX <= 4) ? CPMPC_FUSED_WAVES_F32 : 1))
+
 // SHARED: the batch shares one parameter set -> the model constants stay wave-uniform (scalar registers)
 template <typename R, typename M, int SP, int L, bool SHARED>
-__global__ CPMPC_FUSED_BOUNDS void fused_sqp_kernel(const SolverArgs<R, M> a, const int max_iters) {
+__global__ CPMPC_FUSED_BOUNDS_S CPMPC_FUSED_EXTRA_ATTR void fused_sqp_kernel(const SolverArgs<R, M> a, const int max_iters) {
   constexpr int NX = M::NX;
   constexpr int PPW = 64 / L;  // problems per wave
+  constexpr bool kLean = fused_lean<R, M, SP>();
   __shared__ R lds_u[SP * 64];
   __shared__ R lds_du[SP * 64];
   __shared__ XV<R, NX> lds_G[SP * 64];  // column i of my Gamma_s at [i*64 + lane]
-  __shared__ R lds_gw[SP * 64];         // (U^-1 g)_k of my controls
-  __shared__ R lds_id[SP * 64];         // 1/d_k of my controls
+  __shared__ R lds_gw_own[kLean ? 1 : SP * 64];  // (U^-1 g)_k of my controls
+#ifndef CPMPC_FUSED_ID_REGS
+#define CPMPC_FUSED_ID_REGS 0  // 1: 1/d_k in registers (15 KB of LDS, but the full unroll it needs spills 151 values: slower)
+#endif
+  constexpr bool kIdRegs = kLean && CPMPC_FUSED_ID_REGS;
+  __shared__ R lds_id[kIdRegs ? 1 : SP * 64];      // 1/d_k of my controls
+  R* const lds_gw = kLean ? lds_du : lds_gw_own;
+  R id_reg[kIdRegs ? SP : 1];
+  constexpr int kSweepUnroll = kIdRegs ? SP : CPMPC_SWEEP_UNROLL;  // register-held 1/d_k need static indices: full unroll
+#define CPMPC_ID_SET(I, V)                    \
+  do {                                        \
+    if constexpr (kIdRegs) id_reg[I] = (V);   \
+    else lds_id[(I) * 64 + lane] = (V);       \
+  } while (0)
+#define CPMPC_ID_GET(I) (kIdRegs ? id_reg[kIdRegs ? (I) : 0] : lds_id[kIdRegs ? 0 : (I) * 64 + lane])
+#define CPMPC_SWEEP_PRAGMA _Pragma("unroll kSweepUnroll")
+// with the sweeps fully unrolled the scheduler hoists all ten controls' LDS reads to the top and spills; a scheduling
+// barrier per control keeps the live ranges those of the rolled loop
+#define CPMPC_SWEEP_FENCE()                                     \
+  do {                                                          \
+    if constexpr (kIdRegs) __builtin_amdgcn_sched_barrier(0);   \
+  } while (0)
 #define CPMPC_FUSED_MAT2_POW(T, E) mat2_pow<R, (E)>(T)
 #include "mpc_fused_body.inc"
 #undef CPMPC_FUSED_MAT2_POW
+#undef CPMPC_SWEEP_PRAGMA
+#undef CPMPC_SWEEP_FENCE
+#undef CPMPC_ID_SET
+#undef CPMPC_ID_GET
 }
 
 // The same kernel for a state spacing without a compiled specialisation: SP is a.SP at run time, the LDS arrays are
@@ -233,9 +281,17 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_dyn_kernel(const SolverArgs<R, M> a
   R* lds_du = lds_u + (size_t)SP * 64;
   R* lds_gw = lds_du + (size_t)SP * 64;
   R* lds_id = lds_gw + (size_t)SP * 64;
+#define CPMPC_ID_SET(I, V) lds_id[(I) * 64 + lane] = (V)
+#define CPMPC_ID_GET(I) (lds_id[(I) * 64 + lane])
+#define CPMPC_SWEEP_PRAGMA _Pragma("unroll 5")
+#define CPMPC_SWEEP_FENCE() do { } while (0)
 #define CPMPC_FUSED_MAT2_POW(T, E) mat2_pow_rt<R>(T, (E))
 #include "mpc_fused_body.inc"
 #undef CPMPC_FUSED_MAT2_POW
+#undef CPMPC_SWEEP_PRAGMA
+#undef CPMPC_SWEEP_FENCE
+#undef CPMPC_ID_SET
+#undef CPMPC_ID_GET
 }
 
 }  // namespace cpmpc

@@ -1,0 +1,73 @@
+"""Closed-loop soak at batch scale: `--ticks` MPC ticks of `--batch` controllers -- warm-started
+re-plan at reference defaults (8 iterations, exits enabled) + batched plant step -- with a status histogram per tick.
+The reference's own closed-loop criterion (optimization_test.cc:44-46: never QP_INDEFINITE / MAX_LAMBDA; :63-66: upright
+and still at the end) applied to every controller of the batch.  Writes one JSON file.
+Run on the GPU box from the repo root:  python tools/soak.py --dtype f64 --ticks 1000 --out profiles/r03_soak_f64.json"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+pkg = importlib.import_module("cart-pole-mpc_amd")
+DYN_UI = [1.0, 0.1, 0.25, 9.81, 0.05, 0.1, 0.02, 0.8, 100.0]
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--dtype", choices=["f32", "f64"], default="f64")
+ap.add_argument("--batch", type=int, default=262144)
+ap.add_argument("--ticks", type=int, default=1000)
+ap.add_argument("--start", choices=["near-upright", "anywhere"], default="anywhere")
+ap.add_argument("--out", default=None)
+args = ap.parse_args()
+dt = torch.float32 if args.dtype == "f32" else torch.float64
+B = args.batch
+rng = np.random.default_rng(7)
+if args.start == "near-upright":
+    x0 = np.stack([rng.uniform(-0.3, 0.3, B), np.pi / 2 + rng.uniform(-0.4, 0.4, B), rng.uniform(-0.5, 0.5, B), rng.uniform(-1, 1, B)])
+else:   # the benchmark's distribution: any pole angle (swing-up for most)
+    x0 = np.stack([rng.uniform(-0.6, 0.6, B), rng.uniform(-np.pi, np.pi, B), rng.uniform(-1, 1, B), rng.uniform(-3, 3, B)])
+sim = pkg.BatchSimulator(B, dtype=dt, device=0)
+sim.set_state(torch.tensor(x0, dtype=dt, device="cuda:0"))
+opt = pkg.BatchOptimization(pkg.default_params(), max_batch=B, dtype=dt, device=0)
+out = pkg.BatchOutputs()
+names = pkg.capi.TERM_NAMES
+hist_total = {}
+per_tick = []
+bad_ticks = []
+t0 = time.perf_counter()
+for k in range(args.ticks):
+    o = opt.step(sim.get_state(), DYN_UI, 0.0, want_predicted=False, want_stats=True, out=out)
+    sim.step(DYN_UI, 0.01, o.u[0].contiguous())
+    st = torch.bincount(o.status.long(), minlength=9).cpu().numpy()
+    h = {names[i]: int(st[i]) for i in range(9) if st[i]}
+    for n, v in h.items():
+        hist_total[n] = hist_total.get(n, 0) + v
+    nonfinite_u = int((~torch.isfinite(o.u)).any(dim=0).sum().item())
+    rec = {"tick": k, "status": h, "mean_iterations": float(o.iterations.float().mean().item()), "lanes_with_non_finite_u": nonfinite_u}
+    if any(n in h for n in ("QP_INDEFINITE", "MAX_LAMBDA", "NON_FINITE")) or nonfinite_u:
+        bad_ticks.append(rec)
+    if k < 5 or k % 50 == 0 or k == args.ticks - 1:
+        per_tick.append(rec)
+    if k % 100 == 0:
+        print("tick %d %s its %.2f" % (k, h, rec["mean_iterations"]), flush=True)
+torch.cuda.synchronize()
+wall = time.perf_counter() - t0
+s = sim.get_state().double().cpu().numpy()
+err = np.abs(s[1] - np.pi / 2)
+res = {"dtype": args.dtype, "batch": B, "ticks": args.ticks, "start": args.start, "wall_s": wall, "ms_per_tick": wall / args.ticks * 1e3,
+       "controller_ticks_per_s": B * args.ticks / wall, "status_histogram_total": hist_total,
+       "ticks_with_QP_INDEFINITE_MAX_LAMBDA_or_NON_FINITE": len(bad_ticks), "first_such_ticks": bad_ticks[:20],
+       "final": {"upright_within_1e-3": float((err < 1e-3).mean()), "upright_within_1e-4": float((err < 1e-4).mean()),
+                 "max_abs_pole_angle_error": float(err.max()), "max_abs_b_x": float(np.abs(s[0]).max()),
+                 "max_abs_b_x_dot": float(np.abs(s[2]).max()), "max_abs_th_dot": float(np.abs(s[3]).max()),
+                 "all_finite": bool(np.isfinite(s).all())},
+       "sampled_ticks": per_tick}
+print(json.dumps({k: v for k, v in res.items() if k not in ("sampled_ticks", "first_such_ticks")}, indent=1))
+if args.out:
+    with open(args.out, "w") as fh:
+        json.dump(res, fh, indent=1)
