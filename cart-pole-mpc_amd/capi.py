@@ -81,6 +81,7 @@ class SolverOpts(C.Structure):
         ("b_x_limit", C.c_double),
         ("u_limit", C.c_double),
         ("ls_alpha_growth_backtracked", C.c_double),
+        ("full_step_below", C.c_double),
     ]
 
 

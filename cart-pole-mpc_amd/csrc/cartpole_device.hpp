@@ -323,10 +323,15 @@ struct Math<double> {
     e = ::fma(-x, y, 1.0);
     return ::fma(y, e, y);
   }
+  // Quotients sit in the cold places (penalty update, step-length interpolation, the 4x4 pivots), where the operands are
+  // not guaranteed to be ordinary: v_div_fixup_f64 gives the IEEE result for a zero, infinite, denormal or NaN operand
+  // (b = +-inf -> 0, b = 0 -> +-inf, a denormal b whose seed overflowed -> the correctly signed infinity instead of
+  // inf - inf = NaN), one instruction.  rcp() above stays bare: its callers (the dynamics' den > 0, pivots tested
+  // positive first) guarantee an ordinary operand.
   static __device__ __forceinline__ double div(double a, double b) {
     const double y = rcp(b);
     const double q = a * y;
-    return ::fma(::fma(-b, q, a), y, q);
+    return __builtin_amdgcn_div_fixup(::fma(::fma(-b, q, a), y, q), b, a);
   }
   // sqrt(x) and 1/sqrt(x) together (coupled Goldschmidt iteration from v_rsq_f64): the drag terms need both.
   // x = 0 -> (0, 0): "no drag at rest" (single_pendulum_dynamics.hpp:75-84 guards on 0 < |v|^2).

@@ -78,6 +78,7 @@ extern "C" void cpmpc_default_solver_opts(cpmpc_solver_opts* o) {
   o->b_x_limit = 5.0;  // optimization.cc:320
   o->u_limit = 300.0;  // optimization.cc:327
   o->ls_alpha_growth_backtracked = 2.0;
+  o->full_step_below = 1.0e-4;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -483,6 +484,7 @@ static void fill_args(const cpmpc_solver* s, int64_t B, SolverArgs<R, M>& a) {
   a.shrink_min = (R)o.ls_shrink_min;
   a.alpha_growth = (R)o.ls_alpha_growth;
   a.alpha_growth_bt = (R)o.ls_alpha_growth_backtracked;
+  a.full_step_below = (R)o.full_step_below;
   a.rho = (R)o.penalty_rho;
   a.lam_init = (R)o.lambda_initial;
   a.lam_fail_init = (R)o.lambda_failure_init;

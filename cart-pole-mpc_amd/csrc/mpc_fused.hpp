@@ -110,6 +110,26 @@ __device__ __forceinline__ R group_sum(R v) {
   }
   return v;
 }
+// maximum over the group, identical in all its lanes; a NaN in any lane gives NaN in all of them
+template <typename R, int L>
+__device__ __forceinline__ R group_max(R v) {
+  if constexpr (L == 4) {
+    v = nan_max(v, dpp<kDppQuadXor1>(v));
+    v = nan_max(v, dpp<kDppQuadXor2>(v));
+  } else if constexpr (L == 2) {
+    v = nan_max(v, dpp<kDppQuadXor1>(v));
+  } else if constexpr ((L & (L - 1)) == 0) {
+#pragma unroll
+    for (int off = 1; off < L; off <<= 1) v = nan_max(v, __shfl_xor(v, off));
+  } else {
+    const int gb = (int)threadIdx.x - (int)threadIdx.x % L;
+    R acc = __shfl(v, gb);
+#pragma unroll
+    for (int j = 1; j < L; ++j) acc = nan_max(acc, __shfl(v, gb + j));
+    v = acc;
+  }
+  return v;
+}
 // value of my right / left neighbour lane; callers discard it at the group edge.  Groups whose size divides 16
 // never straddle a DPP row; the others go through the wave shuffle.
 template <typename R, int L>

@@ -95,6 +95,8 @@ typedef struct cpmpc_solver_opts {
   double b_x_limit;
   double u_limit;
   double ls_alpha_growth_backtracked; /* growth used instead of ls_alpha_growth when the accepted search backtracked */
+  double full_step_below; /* a QP step with |dz|_inf <= this is taken in full without the merit test (local convergence
+                           * safeguard; default 1e-4, 0 disables) */
 } cpmpc_solver_opts;
 
 void cpmpc_default_params(cpmpc_params* p);           /* optimization.hpp:12-48 defaults */

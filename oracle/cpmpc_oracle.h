@@ -75,6 +75,7 @@ typedef struct orc_solver_opts {
   double b_x_limit;                   /* 5.0   (optimization.cc:320) */
   double u_limit;                     /* 300.0 (optimization.cc:327) */
   double ls_alpha_growth_backtracked; /* growth used instead of ls_alpha_growth when the accepted search had to backtrack */
+  double full_step_below; /* a QP step with |dz|_inf <= this is taken in full without the merit test (0 disables) */
 } orc_solver_opts;
 
 /* Termination states; names follow mini_opt::NLSTerminationState as used by the reference

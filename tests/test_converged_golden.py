@@ -6,10 +6,12 @@ lands in the same basin reaches the same KKT point of optimization.cc:194-301's 
 
   * the golden points themselves are KKT points of the ORACLE's statement of the problem (orc_problem_eval): the two
     statements of the NLP agree;
-  * the oracle's SQP, run from the reference's initial guess until it stops moving, ends within
-    1e-5 of u* on every near-upright case and on the swing-up cases that land in the same basin;
-  * the GPU (fp64, both pipelines) stops a little further out (near-upright: median 1e-6, worst 6e-5 .. 9e-5): the
-    bounds in the GPU test are the measured ones, with the reason."""
+  * the oracle's SQP, run from the reference's initial guess until it stops moving, ends at u* --
+    to 1e-9, not merely the 1e-5 of the parity bar -- on every near-upright case and on the swing-up cases that land
+    in the same basin;
+  * the GPU (fp64, both pipelines) does the same.
+(Before round 3's full-step rule -- a QP step that is tiny in every component is taken without the merit test -- both
+stalled 1e-7 .. 1e-4 short of u*: the l1 merit cannot resolve the decrease of the last steps and rejected them.)"""
 import json
 import os
 
@@ -52,13 +54,6 @@ def test_golden_points_are_kkt_points_of_the_oracles_problem(orc, cases):
     assert worst_c < 1e-9 and worst_g < 1e-7
 
 
-def _split(cases, errs, objs):
-    """(cases that reached u*, cases in another basin or not converged) and the list of near-upright misses."""
-    hit = [e <= 1e-5 for e in errs]
-    miss_upright = [(c["x0"], e) for c, e, h in zip(cases, errs, hit) if not h and c["kind"] == "near-upright"]
-    return hit, miss_upright
-
-
 def test_oracle_fixed_point_is_the_independent_optimum(orc, cases):
     errs, objs = [], []
     for c in cases:
@@ -67,25 +62,18 @@ def test_oracle_fixed_point_is_the_independent_optimum(orc, cases):
         errs.append(float(np.abs(out.u - np.array(c["u_star"])).max()))
         _, _, f = _kkt_through_oracle(orc, c, out.z)
         objs.append(f)
-    hit, miss_upright = _split(cases, errs, objs)
-    swing = [h for c, h in zip(cases, hit) if c["kind"] == "swing-up"]
-    print("oracle fixed point = u* (<= 1e-5): %d of %d cases (swing-up %d of %d); median |du| on those %.1e" % (
-        sum(hit), len(cases), sum(swing), len(swing), np.median([e for e, h in zip(errs, hit) if h])))
-    assert not miss_upright, miss_upright            # every near-upright problem converges to the independent optimum
-    assert sum(swing) >= 0.75 * len(swing)
-    # A case that misses u* is in another basin or never settled (its objective differs by 20 % and more) -- or it is
-    # a NEAR miss: the objective equal to ~1e-15 relative, u a few 1e-5 .. 1e-4 away.  Those optima are flat: an
-    # objective of ~1.3e3 is resolved to ~3e-13 in double, and along their flattest feasible direction that hides
-    # control changes of up to 1e-4, so a merit-function line search (any, not only this one) stops accepting steps
-    # there, while the independent Newton iteration on the KKT *equations* does not have that limit.  Counted, bounded,
-    # reported; they must stay rare and close.
-    near = []
-    for c, e, h, f in zip(cases, errs, hit, objs):
-        if not h and abs(f - c["objective"]) <= 1e-8 * (1.0 + c["objective"]):
-            near.append((c["x0"], e))
-    print("same basin, stalled near u* at the merit function's resolution:", near)
-    assert all(e <= 3e-4 for _, e in near), near
-    assert len(near) <= 0.05 * len(cases)
+    e = np.array(errs)
+    up = np.array([c["kind"] == "near-upright" for c in cases])
+    hit = e <= 1e-5
+    print("oracle fixed point vs u*: near-upright median %.1e worst %.1e; swing-up within 1e-5: %d of %d; all cases within "
+          "1e-8: %d of %d" % (np.median(e[up]), e[up].max(), hit[~up].sum(), (~up).sum(), (e <= 1e-8).sum(), e.size))
+    assert e[up].max() < 1e-9, sorted(e[up])[-5:]      # every near-upright problem converges TO the independent optimum
+    assert hit[~up].sum() >= 0.75 * (~up).sum()
+    assert (e[hit] <= 1e-8).mean() >= 0.95             # where it gets there at all it gets there properly
+    # a case that misses u* is in another basin or has not settled: its objective differs, or it is still far
+    for c, x, h, f in zip(cases, errs, hit, objs):
+        if not h:
+            assert abs(f - c["objective"]) > 1e-9 * (1.0 + c["objective"]) or x > 1e-5, (c["x0"], x, f, c["objective"])
 
 
 @pytest.mark.gpu
@@ -111,22 +99,18 @@ def test_gpu_fixed_point_is_the_independent_optimum(pkg, orc, cases, pipeline):
         for j, i in enumerate(idx):
             errs[i] = float(np.abs(u[:, j] - np.array(cases[i]["u_star"])).max())
             orc_hit[i] = float(np.abs(u_orc[:, j] - np.array(cases[i]["u_star"])).max()) <= 1e-5
-    hit, miss_upright = _split(cases, errs, None)
-    up = np.array([c["kind"] == "near-upright" for c in cases])
     e = np.array(errs)
-    print("%s: GPU fixed point = u* (<= 1e-5) on %d of %d cases (oracle: %d); near-upright: median %.1e, worst %.1e, "
-          "%d of %d within 1e-5" % (pipeline, sum(hit), len(cases), sum(orc_hit), np.median(e[up]), e[up].max(),
-                                    (e[up] <= 1e-5).sum(), up.sum()))
-    # Measured (MI355X, round 3): 98-101 of 123 within 1e-5 (oracle 115), near-upright median 1e-6, worst 6e-5 (fused) /
-    # 9e-5 (split) against the oracle's 2.5e-7 / 7.6e-6.  Both SQPs stop at exact (bitwise) fixed points a little short
-    # of the optimum: with the l1 penalty grown to ~1e4 a full step raises mu |c|_1 by O(|dz|^2) more than it lowers the
-    # objective (the Maratos effect), the line search cuts the step until nothing moves, and how short of u* that happens
-    # differs between two implementations at the 1e-5 level.  The bound below is what the specification delivers at
-    # its fixed point; the 1e-5 bar of north_star is a bar on the two implementations after the SAME number of
-    # iterations (test_gpu_parity.py), not on the distance of either from the exact optimum.
-    assert e[up].max() < 2e-4 and np.median(e[up]) < 3e-6, sorted(e[up])[-5:]
-    assert (e[up] <= 1e-5).mean() >= 0.6
-    assert sum(hit) >= 0.75 * len(cases)
-    # where the oracle's SQP reaches u* within 1e-5, the GPU's is never far
-    far = [(c["x0"], x) for c, x, oh in zip(cases, errs, orc_hit) if oh and x > 3e-4]
-    assert not far, far
+    up = np.array([c["kind"] == "near-upright" for c in cases])
+    hit = e <= 1e-5
+    orc_hit = np.array(orc_hit)
+    print("%s: GPU fixed point vs u*: near-upright median %.1e worst %.1e; within 1e-5: %d of %d (oracle: %d); within 1e-8: %d"
+          % (pipeline, np.median(e[up]), e[up].max(), hit.sum(), e.size, orc_hit.sum(), (e <= 1e-8).sum()))
+    # measured (MI355X, round 3): near-upright median 1.5e-12, worst 1e-10; 110 / 111 of the 123 within 1e-5 (oracle 113)
+    assert e[up].max() < 1e-8, sorted(e[up])[-5:]
+    assert hit.sum() >= 0.8 * e.size
+    assert (e[hit] <= 1e-8).mean() >= 0.95
+    # where the oracle's SQP reaches u*, the GPU's does too, but for a few swing-up problems whose long iteration the two
+    # implementations finish in different basins (they part at a line-search decision made at rounding level)
+    lost = [(c["x0"], x) for c, x, oh in zip(cases, errs, orc_hit) if oh and x > 1e-5]
+    print("   reached by the oracle's iteration but not by the GPU's:", lost)
+    assert len(lost) <= 0.05 * e.size

@@ -221,5 +221,7 @@ def test_kkt_residual_of_gpu_solutions(pkg, orc, pipeline):
           % (pipeline, feasible.sum(), B, feasible[::2].sum(), B // 2, np.median(kkt[feasible]), kkt[feasible].max()))
     assert feasible[::2].all()                       # every near-upright problem converges
     assert feasible.mean() > 0.9
-    assert (kkt[feasible] < 1e-6).mean() > 0.99      # a stalled flat optimum (test_converged_golden.py) may sit above
-    assert kkt[feasible].max() < 1e-3
+    # measured: median 3.5e-15, max 2.6e-8 (a few swing-up lanes have closed their defects and are still creeping along)
+    assert np.median(kkt[feasible]) < 1e-12
+    assert (kkt[feasible] < 1e-9).mean() > 0.95
+    assert kkt[feasible].max() < 1e-6

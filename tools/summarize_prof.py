@@ -113,8 +113,8 @@ def main():
     mix = {}
     for k, cs in counters.items():
         waves = cs.get("SQ_WAVES", 0)
-        if waves <= 0 or "SQ_INSTS_VALU" not in cs:
-            continue
+        if waves <= 0 or "SQ_INSTS_VALU" not in cs or "SQ_INSTS_VALU_FMA_F32" not in cs:
+            continue   # the mix passes (prof.sh mix1 / mix2) were not run for this workload
         g = lambda name: cs.get(name, 0.0) / waves   # noqa: E731
         m = {"valu": g("SQ_INSTS_VALU"),
              "f32_arith": g("SQ_INSTS_VALU_ADD_F32") + g("SQ_INSTS_VALU_MUL_F32") + g("SQ_INSTS_VALU_FMA_F32"),
