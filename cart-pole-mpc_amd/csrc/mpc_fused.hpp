@@ -167,6 +167,10 @@ __device__ __forceinline__ R group_last(R v, int gbase) {
 #ifndef CPMPC_FUSED_REFINE_F32
 #define CPMPC_FUSED_REFINE_F32 1
 #endif
+// refinement passes of the terminal multipliers for horizons of more than four intervals (fp64)
+#ifndef CPMPC_FUSED_REFINE_LONG
+#define CPMPC_FUSED_REFINE_LONG 2
+#endif
 // unroll factor of the block-local sweep passes (LDS reads of several controls in flight)
 #ifndef CPMPC_SWEEP_UNROLL
 #define CPMPC_SWEEP_UNROLL 5

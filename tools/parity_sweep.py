@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """All-lane parity at scale: GPU fp64 against the CPU oracle over the configurations the tests cover at small batch,
 here at 65 536 - 262 144 problems each (the oracle runs on the host cores the job is granted).  Writes a JSON report
-(default profiles/r02_parity_sweep.json).  Run on a GPU box:  python tools/parity_sweep.py [out.json]"""
+(default profiles/r03_parity_sweep.json).  Run on a GPU box:  python tools/parity_sweep.py [out.json]"""
 import importlib
 import json
 import os
@@ -44,11 +44,16 @@ CASES = [
     ("all terminal rows costs", 131072, dict(NO_TOL, th_final_cost_weight=50.0, b_x_dot_final_cost_weight=0.0, th_dot_final_cost_weight=3.0), DYN_TEST, 0.2, "single", "auto"),
     ("split pipeline, configs[2] shape", 131072, NO_TOL, DYN_UI, 0.0, "single", "split"),
     ("double pendulum (configs[4]), 5 its", 65536, dict(NO_TOL, u_guess_sinusoid_amplitude=0.0), DYN_DOUBLE, 0.0, "double", "auto"),
+    # round 3
+    ("run to the fixed point: 200 its, exits off (the full-step rule at scale)", 32768, dict(NO_TOL, max_iterations=200), DYN_UI, 0.0, "single", "auto"),
+    ("the same, split pipeline", 16384, dict(NO_TOL, max_iterations=200), DYN_UI, 0.0, "single", "split"),
+    ("N=80 sp=10 (8 intervals), 4 its", 32768, dict(NO_TOL, window_length=80, max_iterations=4), DYN_UI, 0.0, "single", "auto"),
+    ("N=160 sp=10 (16 intervals), 3 its", 16384, dict(NO_TOL, window_length=160, max_iterations=3), DYN_UI, 0.0, "single", "auto"),
 ]
 
 
 def main():
-    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r02_parity_sweep.json")
+    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03_parity_sweep.json")
     report = {"threads": THREADS, "cases": []}
     for i, (tag, B, over, dyn, sp, model, pipe) in enumerate(CASES):
         rng = np.random.default_rng(500 + i)
@@ -67,6 +72,8 @@ def main():
         rec = {"case": tag, "batch": B, "pipeline": opt.pipeline(), "lanes_over_1e-5": int((err > 1e-5).sum()),
                "max": float(err.max()), "p99": float(np.quantile(err, 0.99)), "median": float(np.median(err)),
                "status_and_iterations_agree": int(agree.sum()),
+               # single model: even lanes start near upright (they converge), odd ones anywhere (swing-up)
+               "lanes_over_1e-5_among_near_upright_starts": int((err[::2] > 1e-5).sum()) if model == "single" else None,
                "status_histogram": {pkg.capi.TERM_NAMES[int(c)]: int((st_gpu == c).sum()) for c in np.unique(st_gpu)},
                "cpu_oracle_s": round(t_cpu, 2)}
         far = np.nonzero((err > 1e-5) | ~agree)[0]
