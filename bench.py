@@ -14,6 +14,15 @@ the control sequences are gathered to rank 0 over RCCL.  When WORLD_SIZE is not 
 (plain `python bench.py --gpus N`) this process starts the N ranks itself -- before anything touches
 the GPU -- and relays rank 0's line; under `python -m torch.distributed.run` it is one of the ranks.
 
+For N > 1 the line carries every rank's own time per step, its SQP-kernel time and the stand-alone gather
+(`distributed.per_rank`, `distributed.gather_ms`).  `--as-rank R --of W` solves exactly rank R's shard of the W-GPU
+global batch alone on this GPU (no process group; `--parity-lanes K` holds K sampled lanes of it to the oracle).
+The launcher counts GPUs in sysfs (never through the runtime), polls all ranks and ends the run with the first non-zero
+exit code.
+
+The line's `roofline.issue` / `roofline.clock_GHz_measured` come from a child process on a diagnostic build of the same
+kernels (two clock stamps per wave, tools/kernel_clock.py), outside the timed region.
+
 The same line also carries the record of the parity dtype (`fp64`: the reference computes in double
 only, optimization/single_pendulum_dynamics.hpp:185): the same workload at the same batch in fp64,
 timed the same way, with its own roofline and its control sequences compared with the CPU oracle.
