@@ -88,6 +88,7 @@ struct Math<float> {
     s = sqrt(x);
     r = (0.0f < s) ? rcp(s) : 0.0f;
   }
+  static __device__ __forceinline__ float sqrt_only(float x) { return sqrt(x); }
   static __device__ __forceinline__ float fabs(float x) { return ::fabsf(x); }
   static __device__ __forceinline__ float trunc(float x) { return ::truncf(x); }
   static __device__ __forceinline__ float fma(float a, float b, float c) { return ::fmaf(a, b, c); }
@@ -135,7 +136,7 @@ __device__ __forceinline__ double horner(double p, double z, double c) {
 #define CPMPC_F64_COEF_TABLE 1
 #endif
 #if CPMPC_F64_COEF_TABLE
-__constant__ double kCoef64[23] = {
+__constant__ double kCoef64[23] = {  // [0..7] sincos, [8..18] expm1 (tanh), [19..22] the rotation's own (it shares 12, 15, 16)
     2.75573137070700676789e-06,
     -1.98412698298579493134e-04,
     8.33333333332248946124e-03,
@@ -160,6 +161,9 @@ __constant__ double kCoef64[23] = {
     -1.38888888888888888889e-03,
     -0.5,
 };
+// (Reading the table through a pointer made opaque at the top of each routine, so that the loads stay inside the RK4
+// loops instead of being hoisted, spilled and read back with v_readlane, was tried: 27 scalar loads and 17 waits per step
+// replace 18 v_readlane and 22 s_mov -- no gain.)
 #define CPMPC_C64(I, LITERAL) (kCoef64[I])
 #else
 #define CPMPC_C64(I, LITERAL) (LITERAL)
@@ -235,7 +239,7 @@ struct Math<double> {
   // cancels (a saturated friction term with a tiny v_mu multiplies that slope by up to 1e6).
   static __device__ __forceinline__ void tanh_parts(double x, double& num, double& den, double& e2) {
     double y = -2.0 * ::fabs(x);
-    y = (y < -80.0) ? -80.0 : y;
+    y = ::fmax(y, -80.0);  // one v_max_f64 (a NaN argument becomes -80 here; the caller's other terms keep the NaN)
     const double nf = ::rint(y * 1.44269504088896338700e+00);
     double r = ::fma(-nf, 6.93147180369123816490e-01, y);
     r = ::fma(-nf, 1.90821492927058770002e-10, r);
@@ -308,6 +312,7 @@ struct Math<double> {
     s = ::sqrt(x);
     r = (0.0 < s) ? 1.0 / s : 0.0;
   }
+  static __device__ __forceinline__ double sqrt_only(double x) { return ::sqrt(x); }
 #else
   // The compiler's IEEE division is 11 instructions around v_rcp_f64 (two v_div_scale, four refinement fma, the
   // quotient and its residual, v_div_fmas, v_div_fixup) and its sqrt 15 around v_rsq_f64 (range scaling either side);
@@ -353,6 +358,20 @@ struct Math<double> {
     double s, r;
     sqrt_inv(x, s, r);
     return s;
+  }
+  // sqrt alone, for the Jacobian-free dynamics (|v| of the drag term; 1/|v| is only needed by the partials): one
+  // coupled step from the seed (error 2^-23 -> 2^-45) and the residual correction (-> below an ulp), and the zero
+  // argument handled by a floor of 1e-200 (sqrt 1e-100: the drag products it enters vanish with the velocities) instead
+  // of a compare and two selects.  Ten instructions against fifteen.
+  static __device__ __forceinline__ double sqrt_only(double x) {
+    const double xm = ::fmax(x, 1.0e-200);
+    const double y = __builtin_amdgcn_rsq(xm);
+    double g = xm * y;
+    const double h = 0.5 * y;
+    const double e = ::fma(-h, g, 0.5);
+    g = ::fma(g, e, g);
+    const double h1 = ::fma(h, e, h);
+    return ::fma(::fma(-g, g, xm), h1, g);
   }
 #endif
   static __device__ __forceinline__ double fabs(double x) { return ::fabs(x); }
@@ -463,7 +482,7 @@ __device__ __forceinline__ void cartpole_accel_sc(const CartPoleConsts<R>& k, co
     const R idt = r * den;
     const R q = num * idt;
     if (WITH_J) sech2 = R(4) * e2 * (idt * idt);
-    tv = (v < R(0)) ? -q : q;  // (a NaN speed gives a NaN quotient either way)
+    tv = __builtin_copysign(q, v);  // one v_bfi_b32 (q >= 0; a NaN speed gives a NaN quotient either way)
   } else {
     tv = Math<R>::tanh_scaled(v, k.inv_v_mu, k.tanh_k2);
     inv_den = Math<R>::rcp(den);
@@ -475,8 +494,12 @@ __device__ __forceinline__ void cartpole_accel_sc(const CartPoleConsts<R>& k, co
   const R vx = v - Lw * s;
   const R vy = Lw * c;
   const R n2 = vx * vx + vy * vy;
-  R n, inv_n;  // |v| and 1/|v| (0 at rest); inv_n is only used by the partials
-  Math<R>::sqrt_inv(n2, n, inv_n);
+  R n, inv_n = R(0);  // |v| and 1/|v| (0 at rest); inv_n is only used by the partials
+  if (WITH_J) {
+    Math<R>::sqrt_inv(n2, n, inv_n);
+  } else {
+    n = Math<R>::sqrt_only(n2);
+  }
   const R e = Lw - s * v;  // = c*vy - s*vx
   // the generated code guards these with |v|^2 > 0; at |v| = 0 the products are 0 anyway
   const R Dx = k.half_cd * n * vx;
@@ -553,30 +576,47 @@ __device__ __forceinline__ void cartpole_accel(const CartPoleConsts<R>& k, const
   cartpole_accel_sc<R, WITH_J, HAS_EXT>(k, bx, s, c, v, w, u, fe, a_x, a_th, Ja, Jua);
 }
 
-// The pole angle's sine and cosine across the four stages of one RK4 step: stage 1 evaluates them in full and keeps
-// the base; stages 2-4 are a rotation away (Math<R>::sincos_delta) unless some lane of the wave moves further than the
-// kernels cover (|d| > 1 rad within one step: a pole at more than 100 rad/s), which takes the full path for that lane.
+// The pole angle's sine and cosine across the stages of an RK4 step and the steps of a rollout: the first step's stage 1
+// evaluates them in full and keeps the base; everything after is a rotation away (Math<R>::sincos_delta) unless a lane
+// moves further than the kernels cover (|d| > 1 rad within one step: a pole at more than 100 rad/s, or a wrapped angle),
+// which takes the full path for that lane.
 template <typename R>
 struct TrigBase {
   R th0, s0, c0;
+  bool valid = false;  // (th0, s0, c0) hold the previous step's stage-1 pair: this step's stage 1 may rotate from it
 };
+// The far branch of a rotation (|d| > 1 rad, or a NaN) is taken per LANE, never per wave: a problem's arithmetic must
+// not depend on what its neighbours in the wave do (batch-position independence: staged, sharded and stand-alone solves
+// are bitwise equal).
+template <typename R>
+__device__ __forceinline__ void sincos_from_base(const TrigBase<R>& tb, const R th, R& s, R& c) {
+  const R d = th - tb.th0;
+  Math<R>::sincos_delta(tb.s0, tb.c0, d, s, c);
+#ifndef CPMPC_F64_TRIG_NO_FALLBACK  // (defined only to count the main path's instructions in a listing)
+  if (__builtin_expect(!(Math<R>::fabs(d) <= R(1)), 0)) Math<R>::sincos(th, s, c);
+#endif
+}
+#ifndef CPMPC_F64_TRIG_CHAIN
+#define CPMPC_F64_TRIG_CHAIN 0
+#endif
 template <typename R, int STAGE>
 __device__ __forceinline__ void stage_sincos(TrigBase<R>& tb, const R th, R& s, R& c) {
   if constexpr (Math<R>::kIncrementalTrig) {
     if constexpr (STAGE == 1) {
-      Math<R>::sincos(th, s, c);
+      // consecutive steps of one rollout: this step's angle is within h |w| of the previous step's, so stage 1 rotates
+      // from that pair too (one more rotation per step: the chain's error grows like the square root of its length,
+      // ~1.5 ulp over the ten steps of an interval); a wrapped angle jumps by 2 pi and takes the far branch
+      if (CPMPC_F64_TRIG_CHAIN && tb.valid) {
+        sincos_from_base<R>(tb, th, s, c);
+      } else {
+        Math<R>::sincos(th, s, c);
+      }
       tb.th0 = th;
       tb.s0 = s;
       tb.c0 = c;
+      tb.valid = true;
     } else {
-      // per LANE, never per wave: a problem's arithmetic must not depend on what its neighbours in the wave do
-      // (batch-position independence: staged, sharded and stand-alone solves are bitwise equal).  The far branch also
-      // takes a NaN.
-      const R d = th - tb.th0;
-      Math<R>::sincos_delta(tb.s0, tb.c0, d, s, c);
-#ifndef CPMPC_F64_TRIG_NO_FALLBACK  // (defined only to count the main path's instructions in a listing)
-      if (__builtin_expect(!(Math<R>::fabs(d) <= R(1)), 0)) Math<R>::sincos(th, s, c);
-#endif
+      sincos_from_base<R>(tb, th, s, c);
     }
   } else {
     Math<R>::sincos(th, s, c);

@@ -53,7 +53,9 @@ struct SingleModelHandWritten {
 };
 
 // models without anything to share between the stages of a step
-struct NoStepCache {};
+struct NoStepCache {
+  bool valid = false;
+};
 // the same model on the generated code (README.md:60-71 "Changing the dynamics": edit the Lagrangian in
 // tools/gen_dynamics.py, run it, rebuild with -DCPMPC_GENERATED_SINGLE=1)
 template <typename R>
@@ -176,14 +178,15 @@ __host__ __device__ constexpr bool is_angle(int t) {
 // ------------------------------------------------------------------------------------------------
 // RK4 without sensitivities (integration.hpp:52-62).  x updated in place.
 // ------------------------------------------------------------------------------------------------
+// `sc` carries what consecutive steps of one rollout can share (models.hpp: StepCache): pass the same object to every
+// step of the rollout, start a new rollout with sc.valid = false.
 template <typename R, typename M, bool HAS_EXT>
 __device__ __forceinline__ void rk4_step_m(const typename M::Consts& k, const R h, R (&x)[M::NX], const R u,
-                                           const ExtForce<R>& fe) {
+                                           const ExtForce<R>& fe, typename M::StepCache& sc) {
   constexpr int NX = M::NX, NQ = M::NQ;
   R Ja[NQ][NX], Jua[NQ];
   R a1[NQ], a2[NQ], a3[NQ], a4[NQ], v2[NQ], v3[NQ], v4[NQ], xt[NX];
   const R hh = h / R(2);
-  typename M::StepCache sc;
   M::template accel_stage<false, HAS_EXT, 1>(k, x, u, fe, a1, Ja, Jua, sc);  // k1 = [x_v; a1]
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
@@ -213,6 +216,13 @@ __device__ __forceinline__ void rk4_step_m(const typename M::Consts& k, const R 
     x[i] += h6 * (v1 + v2[i] * R(2) + v3[i] * R(2) + v4[i]);
     x[NQ + i] += h6 * (a1[i] + a2[i] * R(2) + a3[i] * R(2) + a4[i]);
   }
+}
+
+template <typename R, typename M, bool HAS_EXT>
+__device__ __forceinline__ void rk4_step_m(const typename M::Consts& k, const R h, R (&x)[M::NX], const R u,
+                                           const ExtForce<R>& fe) {
+  typename M::StepCache sc;  // a single step: nothing to chain from
+  rk4_step_m<R, M, HAS_EXT>(k, h, x, u, fe, sc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -250,7 +260,7 @@ __device__ __forceinline__ void stage_chain_m(const R (&Ja)[NQ][NX], const R (&J
 template <typename R, typename M, bool HAS_EXT>
 __device__ __forceinline__ void rk4_step_jac_m(const typename M::Consts& k, const R h, R (&x)[M::NX],
                                                const R u, const ExtForce<R>& fe, R (&A)[M::NX][M::NX],
-                                               R (&Bv)[M::NX]) {
+                                               R (&Bv)[M::NX], typename M::StepCache& sc) {
   constexpr int NX = M::NX, NQ = M::NQ;
   const R hh = h / R(2);
   R Ja[NQ][NX], Jua[NQ];
@@ -259,7 +269,6 @@ __device__ __forceinline__ void rk4_step_jac_m(const typename M::Consts& k, cons
   R a1[NQ], a2[NQ], a3[NQ], a4[NQ], v2[NQ], v3[NQ], v4[NQ], xt[NX];
 
   // stage 1
-  typename M::StepCache sc;
   M::template accel_stage<true, HAS_EXT, 1>(k, x, u, fe, a1, Ja, Jua, sc);
 #pragma unroll
   for (int r = 0; r < NQ; ++r) {
@@ -341,6 +350,14 @@ __device__ __forceinline__ void rk4_step_jac_m(const typename M::Consts& k, cons
     x[i] += h6 * (v1 + v2[i] * R(2) + v3[i] * R(2) + v4[i]);
     x[NQ + i] += h6 * (a1[i] + a2[i] * R(2) + a3[i] * R(2) + a4[i]);
   }
+}
+
+template <typename R, typename M, bool HAS_EXT>
+__device__ __forceinline__ void rk4_step_jac_m(const typename M::Consts& k, const R h, R (&x)[M::NX],
+                                               const R u, const ExtForce<R>& fe, R (&A)[M::NX][M::NX],
+                                               R (&Bv)[M::NX]) {
+  typename M::StepCache sc;
+  rk4_step_jac_m<R, M, HAS_EXT>(k, h, x, u, fe, A, Bv, sc);
 }
 
 }  // namespace cpmpc

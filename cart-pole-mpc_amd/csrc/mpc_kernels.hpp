@@ -288,9 +288,10 @@ __global__ __launch_bounds__(256) void prepare_kernel(const SolverArgs<R, M> a) 
   }
   int kk = 0;
   for (int s = 1; s < a.S; ++s) {
+    typename M::StepCache chain;  // consecutive steps share the pole angle's sine / cosine base; re-anchored per interval
     for (int i = 0; i < a.SP; ++i, ++kk) {
       const R u = a.zu[(int64_t)kk * st + p];
-      rk4_step_m<R, M, false>(k, a.dt, x, u, fe);
+      rk4_step_m<R, M, false>(k, a.dt, x, u, fe, chain);
       wrap_angles<R, M>(x);
     }
     a.zx[(int64_t)s * st + p] = pack<R, NX>(x);
@@ -339,12 +340,13 @@ __global__ CPMPC_LIN_BOUNDS void linearize_kernel(const SolverArgs<R, M> a, cons
 
   const R* zu = zu_in + (int64_t)(s * SP) * st;
   R u_next = zu[p];
+  typename M::StepCache chain;  // consecutive steps of the interval share the sine / cosine base (models.hpp)
 #pragma unroll 1
   for (int i = 0; i < SP; ++i) {
     const R u = u_next;
     if (i + 1 < SP) u_next = zu[(int64_t)(i + 1) * st + p];  // prefetch the next control
     R A[NX][NX], Bv[NX];
-    rk4_step_jac_m<R, M, false>(k, a.dt, x, u, fe, A, Bv);
+    rk4_step_jac_m<R, M, false>(k, a.dt, x, u, fe, A, Bv, chain);
     // Phi <- A Phi
     R T[NX][NX];
 #pragma unroll
@@ -425,11 +427,12 @@ __global__ __launch_bounds__(64) void linearize_dyn_kernel(const SolverArgs<R, M
 
   const R* zu = zu_in + (int64_t)s * SP * st;
   XV<R, NX>* gam = a.Gam + (int64_t)s * SP * st;
+  typename M::StepCache chain;
 #pragma unroll 1
   for (int i = 0; i < SP; ++i) {
     const R u = zu[(int64_t)i * st + p];
     R A[NX][NX], Bv[NX];
-    rk4_step_jac_m<R, M, false>(k, a.dt, x, u, fe, A, Bv);
+    rk4_step_jac_m<R, M, false>(k, a.dt, x, u, fe, A, Bv, chain);
     R T[NX][NX];
 #pragma unroll
     for (int r = 0; r < NX; ++r)
@@ -514,6 +517,7 @@ __device__ __forceinline__ void merit_eval(const SolverArgs<R, M>& a, const type
     R x[NX];
 #pragma unroll
     for (int t = 0; t < NX; ++t) x[t] = xs[t];
+    typename M::StepCache chain;  // per interval, as in the linearisation
     for (int i = 0; i < a.SP; ++i, ++kk) {
       const R u = clampr(u_raw, -a.u_lim, a.u_lim);
       if (kk + 1 < a.N)  // prefetch the next control of the trial point
@@ -523,7 +527,7 @@ __device__ __forceinline__ void merit_eval(const SolverArgs<R, M>& a, const type
       const R rd = a.wd * (u_before - u);  // (u_{k-1} - u_k) w; for k = 0 it is -(u_0 - u_prev) w
       f += ru * ru + rd * rd;
       u_before = u;
-      rk4_step_m<R, M, false>(k, a.dt, x, u, fe);
+      rk4_step_m<R, M, false>(k, a.dt, x, u, fe, chain);
     }
     wrap_angles<R, M>(x);
     trial_node<R, M>(a, s + 1, p, alpha, xs);  // next node of the trial point
@@ -1035,11 +1039,13 @@ __global__ __launch_bounds__(256) void finalize_kernel(const SolverArgs<R, M> a)
 #pragma unroll
     for (int t = 0; t < NX; ++t) x[t] = a.x0[t * ob + p];
     R u_next = a.zu[p];
+    typename M::StepCache chain;
     for (int kk = 0; kk < a.N; ++kk) {
       const R u = u_next;
       if (kk + 1 < a.N) u_next = a.zu[(int64_t)(kk + 1) * st + p];
       if (a.u_out) a.u_out[(int64_t)kk * ob + p] = u;
-      rk4_step_m<R, M, false>(k, a.dt, x, u, fe);
+      if (kk % 8 == 0) chain.valid = false;  // re-anchor the sine / cosine chain with a full evaluation every 8 steps
+      rk4_step_m<R, M, false>(k, a.dt, x, u, fe, chain);
       wrap_angles<R, M>(x);
 #pragma unroll
       for (int t = 0; t < NX; ++t) a.pred_out[((int64_t)kk * NX + t) * ob + p] = x[t];
@@ -1189,9 +1195,11 @@ __global__ __launch_bounds__(64) void sim_kernel(int64_t B, typename M::Consts k
   // the host evaluates the reference's `while (dt > 0) { SubStep(min(dt, 0.001)); dt -= 0.001; }`
   // in double and passes the count and the last step, so f32 and f64 take the same sub-steps
   const R internal_dt = R(0.001);
+  typename M::StepCache chain;
   for (int i = 0; i < n_sub; ++i) {
     const R h = (i + 1 == n_sub) ? h_last : internal_dt;
-    rk4_step_m<R, M, true>(k, h, xs, uu, fe);
+    if (i % 8 == 0) chain.valid = false;  // re-anchor the sine / cosine chain every 8 sub-steps
+    rk4_step_m<R, M, true>(k, h, xs, uu, fe, chain);
     wrap_angles<R, M>(xs);
   }
 #pragma unroll

@@ -4,7 +4,7 @@
 # bench.py --dtype f64, 60 steps each, twice round-robin
 cd "$(dirname "$0")/.."
 for rep in 1 2; do
-for v in default notable norotate nomerge r2math; do
+for v in ${VARIANTS:-default notable norotate nomerge r2math}; do
   if [ "$v" = default ]; then unset CPMPC_LIB; else export CPMPC_LIB=$PWD/tools/_build/lib_$v/libcpmpc.so; fi
   python bench.py --dtype f64 --steps 60 --no-variants --no-cpu-baseline --no-clock --no-fp64 2>/dev/null | python -c "
 import json,sys
