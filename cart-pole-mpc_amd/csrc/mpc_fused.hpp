@@ -171,6 +171,13 @@ __device__ __forceinline__ R group_last(R v, int gbase) {
 #ifndef CPMPC_FUSED_REFINE_LONG
 #define CPMPC_FUSED_REFINE_LONG 2
 #endif
+// the Gamma update loop of the linearisation reads one column ahead (default: fp64 only; -DCPMPC_FUSED_GAMMA_AHEAD_ALL=0/1
+// forces it off / on for both dtypes)
+#ifdef CPMPC_FUSED_GAMMA_AHEAD_ALL
+#define CPMPC_FUSED_GAMMA_AHEAD(R) (CPMPC_FUSED_GAMMA_AHEAD_ALL != 0)
+#else
+#define CPMPC_FUSED_GAMMA_AHEAD(R) (sizeof(R) == 8)
+#endif
 // unroll factor of the block-local sweep passes (LDS reads of several controls in flight)
 #ifndef CPMPC_SWEEP_UNROLL
 #define CPMPC_SWEEP_UNROLL 5

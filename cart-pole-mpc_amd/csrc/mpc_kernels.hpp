@@ -199,10 +199,11 @@ __device__ __forceinline__ R clampr(R v, R lo, R hi) {
   return v < lo ? lo : (v > hi ? hi : v);
 }
 
-// maximum that a NaN operand poisons for good (|dz|_inf of the full-step rule: a NaN component must read "not tiny")
+// running maximum for |dz|_inf of the full-step rule: one v_max.  (The hardware maximum drops a NaN operand; a step with a
+// NaN component has made the directional quantities non-finite and terminated the problem before the rule is consulted.)
 template <typename R>
 __device__ __forceinline__ R nan_max(R a, R b) {
-  return (a != a || b != b) ? (a + b) : ((a < b) ? b : a);
+  return (sizeof(R) == 8) ? (R)__builtin_fmax((double)a, (double)b) : (R)__builtin_fmaxf((float)a, (float)b);
 }
 
 // wrap the pole angles of a state / state difference

@@ -8,10 +8,10 @@ cd "$R"
 O=gpurun_out/r03f
 mkdir -p $O
 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"
-./tools/prof.sh r03c > $O/prof_f32.log 2>&1; echo "prof f32 rc=$?"
-./tools/prof.sh r03c_f64 --dtype f64 > $O/prof_f64.log 2>&1; echo "prof f64 rc=$?"
-./tools/prof_workload.sh r03c_closed_loop closed_loop > $O/prof_cl.log 2>&1; echo "prof closed loop rc=$?"
-./tools/prof_workload.sh r03c_double_f32 double > $O/prof_double.log 2>&1; echo "prof double rc=$?"
+./tools/prof.sh r03d > $O/prof_f32.log 2>&1; echo "prof f32 rc=$?"
+./tools/prof.sh r03d_f64 --dtype f64 > $O/prof_f64.log 2>&1; echo "prof f64 rc=$?"
+./tools/prof_workload.sh r03d_closed_loop closed_loop > $O/prof_cl.log 2>&1; echo "prof closed loop rc=$?"
+./tools/prof_workload.sh r03d_double_f32 double > $O/prof_double.log 2>&1; echo "prof double rc=$?"
 python tools/kernel_clock.py --seconds 3 --out $O/kernel_clock.json > $O/kernel_clock.log 2>&1; echo "clock rc=$?"
 ./tools/ubench/clock --seconds 1 > $O/clock_ubench.jsonl 2> /dev/null; echo "ubench rc=$?"
 python tools/soak.py --dtype f32 --ticks 1000 --out $O/soak_f32.json > $O/soak_f32.log 2>&1; echo "soak f32 rc=$?"
