@@ -57,7 +57,12 @@ def main():
 
     # kernel stats
     stats = {}
-    for path in glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv")):
+    def newest(pattern):
+        """The most recent file matching the pattern (a tag profiled twice leaves both runs' files behind)."""
+        found = sorted(glob.glob(pattern), key=os.path.getmtime)
+        return found[-1:]
+
+    for path in newest(os.path.join(src, "kt", "*", "*_kernel_stats.csv")):
         with open(path) as fh, open(os.path.join(out_dir, tag + "_kernel_stats.csv"), "w") as out:
             rd = csv.reader(fh)
             wr = csv.writer(out)
@@ -71,7 +76,7 @@ def main():
     # counters
     counters = defaultdict(dict)
     for sub in ("fetch", "write", "sq", "sq2", "mix1", "mix2"):
-        for path in glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")):
+        for path in newest(os.path.join(src, sub, "*", "*_counter_collection.csv")):
             for k, cs in read_counters(path).items():
                 for c, vals in cs.items():
                     counters[k][c] = sum(vals) / len(vals)
