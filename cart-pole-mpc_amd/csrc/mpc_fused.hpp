@@ -69,9 +69,18 @@ __device__ __forceinline__ Mat2<R> mat2_pow_rt(const Mat2<R>& t, int e) {  // ru
 // row shifts and, for L = 4 (one quad) and L = 2, sums and broadcasts are quad permutes.  DPP moves are VALU
 // operand modifiers: no trip through the LDS crossbar as for ds_bpermute (__shfl), which matters in the
 // boundary chains where every move is on the critical path.
+#ifndef CPMPC_DPP_NO_OLD
+#define CPMPC_DPP_NO_OLD 1
+#endif
 template <int CTRL>
 __device__ __forceinline__ int dpp32(int v) {
+#if CPMPC_DPP_NO_OLD
+  // every lane is written (all rows and banks enabled; a lane whose source falls off its row reads 0), so there is no
+  // previous value to preserve and no `v_mov_b32 dst, 0` in front of the move
+  return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true);
+#else
   return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+#endif
 }
 template <int CTRL>
 __device__ __forceinline__ float dpp(float v) {

@@ -70,6 +70,20 @@ __global__ __launch_bounds__(64) void k(float* out, Stamp* st, int iters) {
         asm volatile("v_add_f64 %0, %0, %8\n v_add_f64 %1, %1, %8\n v_add_f64 %2, %2, %8\n v_add_f64 %3, %3, %8\n"
                      "v_add_f64 %4, %4, %8\n v_add_f64 %5, %5, %8\n v_add_f64 %6, %6, %8\n v_add_f64 %7, %7, %8\n"
                      : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(cd));
+      } else if (MODE == 11) {  // packed fp32 fma: two fp32 results per instruction, on register pairs
+        asm volatile("v_pk_fma_f32 %0, %0, %8, %8\n v_pk_fma_f32 %1, %1, %8, %8\n v_pk_fma_f32 %2, %2, %8, %8\n v_pk_fma_f32 %3, %3, %8, %8\n"
+                     "v_pk_fma_f32 %4, %4, %8, %8\n v_pk_fma_f32 %5, %5, %8, %8\n v_pk_fma_f32 %6, %6, %8, %8\n v_pk_fma_f32 %7, %7, %8, %8\n"
+                     : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(cd));
+      } else if (MODE == 12) {  // packed and plain fp32 fma alternating (what a partly packed kernel would issue)
+        asm volatile("v_pk_fma_f32 %0, %0, %8, %8\n v_fma_f32 %4, %4, %9, %10\n v_pk_fma_f32 %1, %1, %8, %8\n v_fma_f32 %5, %5, %9, %10\n"
+                     "v_pk_fma_f32 %2, %2, %8, %8\n v_fma_f32 %6, %6, %9, %10\n v_pk_fma_f32 %3, %3, %8, %8\n v_fma_f32 %7, %7, %9, %10\n"
+                     : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(cd), "v"(m), "v"(c));
+      } else if (MODE == 13) {  // packed fp32 fma with one operand broadcast from the low half (op_sel_hi)
+        asm volatile("v_pk_fma_f32 %0, %8, %0, %8 op_sel_hi:[0,1,1]\n v_pk_fma_f32 %1, %8, %1, %8 op_sel_hi:[0,1,1]\n"
+                     "v_pk_fma_f32 %2, %8, %2, %8 op_sel_hi:[0,1,1]\n v_pk_fma_f32 %3, %8, %3, %8 op_sel_hi:[0,1,1]\n"
+                     "v_pk_fma_f32 %4, %8, %4, %8 op_sel_hi:[0,1,1]\n v_pk_fma_f32 %5, %8, %5, %8 op_sel_hi:[0,1,1]\n"
+                     "v_pk_fma_f32 %6, %8, %6, %8 op_sel_hi:[0,1,1]\n v_pk_fma_f32 %7, %8, %7, %8 op_sel_hi:[0,1,1]\n"
+                     : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(cd));
       } else if (MODE == 10) {  // v_mul_f32 with a DPP operand (the group traffic of the fused kernel)
         asm volatile("v_mul_f32_dpp %0, %0, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
                      "v_mul_f32_dpp %1, %1, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
@@ -163,12 +177,24 @@ void run(const char* name, int blocks) {
 }
 
 int main(int argc, char** argv) {
-  for (int i = 1; i + 1 < argc; ++i)
-    if (!strcmp(argv[i], "--seconds")) g_seconds = atof(argv[i + 1]);
+  bool packed_only = false;
+  for (int i = 1; i < argc; ++i) {
+    if (!strcmp(argv[i], "--seconds") && i + 1 < argc) g_seconds = atof(argv[i + 1]);
+    if (!strcmp(argv[i], "--packed")) packed_only = true;  // only the packed-fp32 modes (and plain fma beside them)
+  }
   hipDeviceProp_t prop;
   hipGetDeviceProperties(&prop, 0);
   printf("{\"device\": \"%s\", \"arch\": \"%s\", \"clockRate_kHz\": %d, \"CUs\": %d}\n", prop.name, prop.gcnArchName,
          prop.clockRate, prop.multiProcessorCount);
+  if (packed_only) {
+    for (int blocks : {1024, 2048, 3072, 4096}) {
+      run<0>("v_fma_f32", blocks);
+      run<11>("v_pk_fma_f32", blocks);
+      run<13>("v_pk_fma_f32 op_sel_hi broadcast", blocks);
+      run<12>("v_pk_fma_f32 + v_fma_f32 alternating", blocks);
+    }
+    return 0;
+  }
   for (int blocks : {1024, 2048, 3072, 4096, 8192}) {
     run<0>("v_fma_f32", blocks);
     run<1>("v_fma_f32 dependent", blocks);
