@@ -257,6 +257,47 @@ __device__ __forceinline__ void stage_chain_m(const R (&Ja)[NQ][NX], const R (&J
   }
 }
 
+// The same product for stage 2, where D = D_1 = [[0 I],[Ja1]] and d = [0; Jua1] are known by their structure: the products
+// with the zeros and ones of the top rows are not issued (the compiler may not drop a multiplication by a literal 0.0 on
+// its own: 0 * inf).  Same operations in the same order on everything that is not such a constant, so a finite result has
+// the bits stage_chain_m gives.
+template <typename R, int NX, int NQ>
+__device__ __forceinline__ void stage_chain_first_m(const R (&Ja)[NQ][NX], const R (&Jua)[NQ], const R a,
+                                                    const R (&Ja1)[NQ][NX], const R (&Jua1)[NQ], R (&Dn)[NX][NX],
+                                                    R (&dn)[NX]) {
+#pragma unroll
+  for (int c = 0; c < NX; ++c) {
+#pragma unroll
+    for (int r = 0; r < NQ; ++r) Dn[r][c] = a * Ja1[r][c] + (c == NQ + r ? R(1) : R(0));
+#pragma unroll
+    for (int r = 0; r < NQ; ++r) {
+      R acc;
+      if (c >= NQ) {
+        acc = Ja[r][c - NQ];  // the one of the identity block
+#pragma unroll
+        for (int kk = 0; kk < NQ; ++kk) acc += Ja[r][NQ + kk] * Ja1[kk][c];
+      } else {
+        acc = Ja[r][NQ] * Ja1[0][c];
+#pragma unroll
+        for (int kk = 1; kk < NQ; ++kk) acc += Ja[r][NQ + kk] * Ja1[kk][c];
+      }
+      Dn[NQ + r][c] = Ja[r][c] + a * acc;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < NQ; ++r) {
+    dn[r] = a * Jua1[r];
+    R acc = Ja[r][NQ] * Jua1[0];
+#pragma unroll
+    for (int kk = 1; kk < NQ; ++kk) acc += Ja[r][NQ + kk] * Jua1[kk];
+    dn[NQ + r] = a * acc + Jua[r];
+  }
+}
+
+#ifndef CPMPC_RK4_STAGE2_STRUCTURED
+#define CPMPC_RK4_STAGE2_STRUCTURED 1
+#endif
+
 template <typename R, typename M, bool HAS_EXT>
 __device__ __forceinline__ void rk4_step_jac_m(const typename M::Consts& k, const R h, R (&x)[M::NX],
                                                const R u, const ExtForce<R>& fe, R (&A)[M::NX][M::NX],
@@ -294,8 +335,22 @@ __device__ __forceinline__ void rk4_step_jac_m(const typename M::Consts& k, cons
     xt[i] = x[i] + x[NQ + i] * hh;
     xt[NQ + i] = v2[i];
   }
+#if CPMPC_RK4_STAGE2_STRUCTURED
+  {
+    R Ja1[NQ][NX], Jua1[NQ];
+#pragma unroll
+    for (int r = 0; r < NQ; ++r) {
+#pragma unroll
+      for (int c = 0; c < NX; ++c) Ja1[r][c] = Ja[r][c];
+      Jua1[r] = Jua[r];
+    }
+    M::template accel_stage<true, HAS_EXT, 2>(k, xt, u, fe, a2, Ja, Jua, sc);
+    stage_chain_first_m<R, NX, NQ>(Ja, Jua, hh, Ja1, Jua1, Dn, dn);
+  }
+#else
   M::template accel_stage<true, HAS_EXT, 2>(k, xt, u, fe, a2, Ja, Jua, sc);
   stage_chain_m<R, NX, NQ>(Ja, Jua, hh, D, d, Dn, dn);
+#endif
 #pragma unroll
   for (int r = 0; r < NX; ++r) {
 #pragma unroll
