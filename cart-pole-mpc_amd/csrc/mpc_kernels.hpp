@@ -258,14 +258,8 @@ __global__ __launch_bounds__(256) void prepare_kernel(const SolverArgs<R, M> a) 
   const ExtForce<R> fe{R(0), R(0), R(0)};
 
   // BuildProblem reads u_prev before the previous solution is overwritten (optimization.cc:288-291)
-  R u_prev = R(0);
-  if ((int64_t)p < a.prev_B) {  // per problem: a controller with no previous solution starts cold (optimization.cc:46-68)
-    u_prev = a.zu[p];
-    // shift the controls left by one, duplicate the last (optimization.cc:54-57)
-    for (int kk = 0; kk + 1 < a.N; ++kk) a.zu[(int64_t)kk * st + p] = a.zu[(int64_t)(kk + 1) * st + p];
-  } else {
-    for (int kk = 0; kk < a.N; ++kk) a.zu[(int64_t)kk * st + p] = a.sin_table[kk];
-  }
+  const bool warm = (int64_t)p < a.prev_B;  // per problem: a controller with no previous solution starts cold (optimization.cc:46-68)
+  const R u_prev = warm ? a.zu[p] : R(0);
   a.sc[SC_UPREV * st + p] = u_prev;
   a.sc[SC_LAMBDA * st + p] = a.lam_init;
   a.sc[SC_MU * st + p] = a.mu_init;
@@ -278,7 +272,15 @@ __global__ __launch_bounds__(256) void prepare_kernel(const SolverArgs<R, M> a) 
   a.ist[IS_LS_EVALS * st + p] = 0;
   a.ist[IS_FAILED * st + p] = 0;
 
-  // FillInitialGuess (optimization.cc:333-351): roll the states, wrapping after every step
+  // The guess of the controls -- warm: the previous ones shifted left by one, the last duplicated (optimization.cc:54-57),
+  // cold: the sinusoid (optimization.cc:58-68) -- is written WHILE the states are rolled (FillInitialGuess,
+  // optimization.cc:333-351, wrapping after every step), each control fetched one step before it is integrated: the shift
+  // in place reads index k+2 while it writes index k, and no step waits for the load of a value stored just before it
+  // (that round trip per step was 45 % of this kernel's wave-cycles).
+  auto guess_u = [&](int i) -> R {  // control i of the new guess, i < N
+    if (warm) return a.zu[(int64_t)((i + 1 < a.N) ? i + 1 : a.N - 1) * st + p];
+    return a.sin_table[i];
+  };
   R x[NX];
 #pragma unroll
   for (int t = 0; t < NX; ++t) x[t] = a.x0[t * a.B + p];
@@ -288,10 +290,14 @@ __global__ __launch_bounds__(256) void prepare_kernel(const SolverArgs<R, M> a) 
     for (int t = 0; t < NX; ++t) a.guess_out[(int64_t)t * a.B + p] = x[t];
   }
   int kk = 0;
+  R u_next = guess_u(0);
   for (int s = 1; s < a.S; ++s) {
     typename M::StepCache chain;  // consecutive steps share the pole angle's sine / cosine base; re-anchored per interval
     for (int i = 0; i < a.SP; ++i, ++kk) {
-      const R u = a.zu[(int64_t)kk * st + p];
+      const R u = u_next;
+      if (kk + 1 < a.N) u_next = guess_u(kk + 1);
+      a.zu[(int64_t)kk * st + p] = u;
+      if (a.guess_out) a.guess_out[(int64_t)(NX * a.S + kk) * a.B + p] = u;
       rk4_step_m<R, M, false>(k, a.dt, x, u, fe, chain);
       wrap_angles<R, M>(x);
     }
@@ -301,8 +307,6 @@ __global__ __launch_bounds__(256) void prepare_kernel(const SolverArgs<R, M> a) 
       for (int t = 0; t < NX; ++t) a.guess_out[(int64_t)(NX * s + t) * a.B + p] = x[t];
     }
   }
-  if (a.guess_out)
-    for (int i = 0; i < a.N; ++i) a.guess_out[(int64_t)(NX * a.S + i) * a.B + p] = a.zu[(int64_t)i * st + p];
 }
 
 // ------------------------------------------------------------------------------------------------
