@@ -669,7 +669,7 @@ static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* 
   ProfSpan sp;
 
   span_begin(s, CPMPC_KERNEL_PREPARE, stream, &sp);
-  hipLaunchKernelGGL((prepare_kernel<R, M>), dim3((unsigned)((B + 255) / 256)), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL((prepare_kernel<R, M>), dim3((unsigned)((B + CPMPC_PF_BLOCK - 1) / CPMPC_PF_BLOCK)), dim3(CPMPC_PF_BLOCK), 0, stream, a);
   span_end(s, stream, &sp);
 
   if (use_fused(s)) {
@@ -725,7 +725,7 @@ static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* 
   }
 
   span_begin(s, CPMPC_KERNEL_FINALIZE, stream, &sp);
-  hipLaunchKernelGGL((finalize_kernel<R, M>), dim3((unsigned)((B + 255) / 256)), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL((finalize_kernel<R, M>), dim3((unsigned)((B + CPMPC_PF_BLOCK - 1) / CPMPC_PF_BLOCK)), dim3(CPMPC_PF_BLOCK), 0, stream, a);
   span_end(s, stream, &sp);
 
   HIP_TRY(hipGetLastError());

@@ -23,6 +23,11 @@
 
 #include "models.hpp"
 
+// threads per workgroup of the one-thread-per-problem kernels before and after the SQP (prepare, finalize)
+#ifndef CPMPC_PF_BLOCK
+#define CPMPC_PF_BLOCK 256
+#endif
+
 namespace cpmpc {
 
 constexpr int kTermNone = 0;
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(1024) void compact_active_kernel(const int32_t* sta
 }
 
 template <typename R, typename M>
-__global__ __launch_bounds__(256) void prepare_kernel(const SolverArgs<R, M> a) {  // 256-thread workgroups, as finalize
+__global__ __launch_bounds__(CPMPC_PF_BLOCK) void prepare_kernel(const SolverArgs<R, M> a) {  // workgroups as finalize
   constexpr int NX = M::NX;
   const unsigned p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= a.B) return;
@@ -1015,7 +1020,7 @@ __global__ CPMPC_QPLS_BOUNDS void qp_ls_kernel(const SolverArgs<R, M> a) {
 template <typename R, typename M>
 // launched with 256-thread workgroups: 4x fewer workgroups to dispatch for a kernel that is a single round of waves
 // (measured 92 -> 80 us at B = 262 144)
-__global__ __launch_bounds__(256) void finalize_kernel(const SolverArgs<R, M> a) {
+__global__ __launch_bounds__(CPMPC_PF_BLOCK) void finalize_kernel(const SolverArgs<R, M> a) {
   constexpr int NX = M::NX;
   const unsigned p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= a.B) return;
