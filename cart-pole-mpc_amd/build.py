@@ -11,7 +11,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libcpmpc.so")
-SOURCES = [os.path.join(CSRC, "cpmpc_api.hip")]
+# five translation units, compiled in parallel: the C-ABI (no device code) and the kernels of each (dtype, model) pair
+UNITS = ["cpmpc_api", "engine_f32_single", "engine_f64_single", "engine_f32_double", "engine_f64_double"]
+SOURCES = [os.path.join(CSRC, u + ".hip") for u in UNITS]
+# -fno-slp-vectorize: on gfx950 a v_pk_fma_f32 issues at ~1.8x the cost of a v_fma_f32 (tools/ubench/pk.hip), so the
+# SLP vectoriser's packing plus its pairing moves is a net loss here (measured 91M -> 104M re-plans/s, 255 -> 189 VGPRs
+# for the fused SQP kernel)
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC"]
 
 
 def _deps():
@@ -61,34 +67,49 @@ def build_variant(name, flags, force=False, verbose=False):
         fcntl.flock(lock, fcntl.LOCK_EX)
         if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in _deps()):
             return out
-        tmp = out + ".tmp.%d" % os.getpid()
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC"] + \
-            list(flags) + ["-o", tmp] + SOURCES
+        _compile_units(out, list(flags), verbose)
+    return out
+
+
+def _compile_units(out, extra_flags, verbose):
+    """hipcc -c every unit (in parallel: the kernels of one (dtype, model) pair take about a minute each), then link.
+    Objects go next to the library; the library itself is replaced atomically."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    objdir = os.path.join(os.path.dirname(out), "obj")
+    os.makedirs(objdir, exist_ok=True)
+    hipcc = _hipcc()
+
+    def one(unit):
+        obj = os.path.join(objdir, "%s.%d.o" % (unit, os.getpid()))
+        cmd = [hipcc] + HIPCC_FLAGS + extra_flags + ["-c", "-o", obj, os.path.join(CSRC, unit + ".hip")]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
-        subprocess.check_call(cmd, stdout=subprocess.DEVNULL if not verbose else None,
-                              stderr=subprocess.DEVNULL if not verbose else None)
-        os.replace(tmp, out)
+        # hipcc's warnings (hundreds of "loop not unrolled" remarks for the run-time-spacing kernels) are shown only when
+        # asked for or when the compilation fails
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0 or verbose:
+            sys.stderr.write(r.stdout)
+        if r.returncode != 0:
+            raise subprocess.CalledProcessError(r.returncode, cmd)
+        return obj
+
+    jobs = int(os.environ.get("CPMPC_BUILD_JOBS", "0")) or min(len(UNITS), os.cpu_count() or 1)
+    with ThreadPoolExecutor(jobs) as ex:
+        objs = list(ex.map(one, UNITS))
+    tmp = out + ".tmp.%d" % os.getpid()
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    os.replace(tmp, out)  # atomic: a concurrent loader never sees a half-written library
+    for o in objs:
+        os.remove(o)
     return out
 
 
 def _compile(verbose):
-    # -fno-slp-vectorize: on gfx950 a v_pk_fma_f32 issues at ~1.8x the cost of a v_fma_f32 (tools/ubench/pk.hip),
-    # so the SLP vectoriser's packing plus its pairing moves is a net loss here (measured 91M -> 104M re-plans/s,
-    # 255 -> 189 VGPRs for the fused SQP kernel)
-    tmp = LIB + ".tmp.%d" % os.getpid()
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC",
-           "-o", tmp] + SOURCES
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    # hipcc's warnings (hundreds of "loop not unrolled" remarks for the run-time-spacing kernels) are shown only when asked
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    if r.returncode != 0 or verbose:
-        sys.stderr.write(r.stdout)
-    if r.returncode != 0:
-        raise subprocess.CalledProcessError(r.returncode, cmd)
-    os.replace(tmp, LIB)  # atomic: a concurrent loader never sees a half-written library
-    return LIB
+    return _compile_units(LIB, [], verbose)
 
 
 HOST = os.path.join(HERE, "host")

@@ -1,8 +1,9 @@
-// cpmpc_api.hip -- C-ABI (include/cpmpc.h) over the gfx950 kernels in mpc_kernels.hpp.
+// cpmpc_api.hip -- C-ABI (include/cpmpc.h) over the gfx950 kernels.
 //
 // Host side of the batched cart-pole MPC hot path.  There is no CPU compute path in this library:
 // every entry point that computes launches HIP kernels and fails with CPMPC_ERR_NO_DEVICE when no
-// gfx950 device is usable.
+// gfx950 device is usable.  This unit holds no device code: the kernels of each (dtype, model) pair live in their own
+// translation unit (engine_<dtype>_<model>.hip) and are reached through its `Engine` table (engine.hpp).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -13,32 +14,20 @@
 #include <string>
 #include <vector>
 
-#include "../../include/cpmpc.h"
-#include "mpc_kernels.hpp"
-#include "mpc_fused.hpp"
-
-using namespace cpmpc;
+#include "engine.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // error text
 // ------------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
 
-static int fail(int code, const char* fmt, ...) {
+int cpmpc_fail(int code, const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof g_err, fmt, ap);
   va_end(ap);
   return code;
 }
-
-#define HIP_TRY(expr)                                                                       \
-  do {                                                                                      \
-    hipError_t e_ = (expr);                                                                 \
-    if (e_ != hipSuccess)                                                                   \
-      return fail(CPMPC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),     \
-                  __FILE__, __LINE__);                                                      \
-  } while (0)
 
 extern "C" const char* cpmpc_last_error(void) { return g_err; }
 
@@ -135,74 +124,9 @@ extern "C" int cpmpc_model_num_params(int model) {
   return (model == CPMPC_MODEL_SINGLE || model == CPMPC_MODEL_DOUBLE) ? model_np(model) : -1;
 }
 
-// run `body` with R and M bound to the (dtype, model) pair
-#define CPMPC_DISPATCH(dtype, model, body)                \
-  do {                                                    \
-    if ((dtype) == CPMPC_F32 && (model) == CPMPC_MODEL_SINGLE) { \
-      using R = float;                                    \
-      using M = SingleModel<float>;                       \
-      body;                                               \
-    } else if ((dtype) == CPMPC_F64 && (model) == CPMPC_MODEL_SINGLE) { \
-      using R = double;                                   \
-      using M = SingleModel<double>;                      \
-      body;                                               \
-    } else if ((dtype) == CPMPC_F32) {                    \
-      using R = float;                                    \
-      using M = DoubleModel<float>;                       \
-      body;                                               \
-    } else {                                              \
-      using R = double;                                   \
-      using M = DoubleModel<double>;                      \
-      body;                                               \
-    }                                                     \
-  } while (0)
-
 // ------------------------------------------------------------------------------------------------
 // the handle
 // ------------------------------------------------------------------------------------------------
-struct ProfSpan {
-  int kernel;
-  hipEvent_t start, stop;
-};
-
-struct cpmpc_solver {
-  cpmpc_params params;
-  cpmpc_solver_opts opts;
-  int dtype;
-  int model;
-  int device;
-  int64_t cap;  // workspace stride (capacity rounded up to a multiple of 64)
-  int N, S, SP, NX, NP, dim;
-  size_t esize;
-  // one allocation, carved into fields
-  void* ws = nullptr;
-  size_t ws_bytes = 0;
-  char *zx, *zu, *dzx, *dzu, *Phi, *Gam, *cs, *Wk, *Tk, *sc;
-  int32_t* ist;
-  void* sin_table = nullptr;
-  int64_t prev_B = 0;  // problems [0, prev_B) hold a previous solution; Reset() -> 0
-  // staging for the *_host entry points (lazily allocated, grown on demand, owned by the handle): a device buffer,
-  // its pinned host mirror and a stream, so that a host-pointer call is one async copy in, the kernels, one async
-  // copy out and a single synchronisation
-  void* stage = nullptr;
-  void* pin = nullptr;
-  size_t stage_bytes = 0;
-  hipStream_t hstream = nullptr;
-  hipEvent_t ev_last = nullptr;  // end of the last device-pointer call on a caller's stream; hstream waits on it
-  bool ev_pending = false;
-  // profiling
-  int profiling = 0;
-  std::vector<ProfSpan> spans;
-  std::vector<ProfSpan> free_spans;
-  double prof_ms[CPMPC_KERNEL_COUNT] = {0, 0, 0, 0, 0};
-  int64_t prof_n[CPMPC_KERNEL_COUNT] = {0, 0, 0, 0, 0};
-  int pipeline = CPMPC_PIPELINE_AUTO;
-  // staged fused pipeline (compaction of the still-active problems between stages); 0/0 = single launch
-  int stage_first = 3, stage_next = 1;
-  bool stage_auto = true;  // default: stage only batches larger than one round of resident waves
-  int32_t* active = nullptr;  // [cap] compacted problem indices, then two counters
-};
-
 // 2: a register-resident linearisation is compiled for this spacing; 1: served by the generic kernel
 // (run-time spacing, O(spacing^2) workspace traffic per interval); 0: not a spacing
 extern "C" int cpmpc_supported_state_spacing(int spacing) {
@@ -372,7 +296,7 @@ extern "C" const char* cpmpc_kernel_name(int kernel) {
   return (kernel >= 0 && kernel < CPMPC_KERNEL_COUNT) ? kKernelNames[kernel] : "?";
 }
 
-static void span_begin(cpmpc_solver* s, int kernel, hipStream_t stream, ProfSpan* cur) {
+void span_begin(cpmpc_solver* s, int kernel, hipStream_t stream, ProfSpan* cur) {
   if (!s->profiling) return;
   if (!s->free_spans.empty()) {
     *cur = s->free_spans.back();
@@ -384,7 +308,7 @@ static void span_begin(cpmpc_solver* s, int kernel, hipStream_t stream, ProfSpan
   cur->kernel = kernel;
   (void)hipEventRecord(cur->start, stream);
 }
-static void span_end(cpmpc_solver* s, hipStream_t stream, ProfSpan* cur) {
+void span_end(cpmpc_solver* s, hipStream_t stream, ProfSpan* cur) {
   if (!s->profiling) return;
   (void)hipEventRecord(cur->stop, stream);
   s->spans.push_back(*cur);
@@ -438,188 +362,6 @@ static void track_caller_stream(cpmpc_solver* s, hipStream_t stream) {
 // ------------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------------
-static inline dim3 grid_for(int64_t threads) { return dim3((unsigned)((threads + 63) / 64)); }
-
-template <typename R, typename M>
-static void fill_args(const cpmpc_solver* s, int64_t B, SolverArgs<R, M>& a) {
-  const cpmpc_params& p = s->params;
-  const cpmpc_solver_opts& o = s->opts;
-  memset((void*)&a, 0, sizeof a);
-  a.B = B;
-  a.stride = s->cap;
-  a.N = s->N;
-  a.S = s->S;
-  a.SP = s->SP;
-  a.iter_cap = (int)p.max_iterations;
-  a.dt = (R)p.control_dt;
-  // rows exist only for strictly positive weights (optimization.cc:270,296)
-  a.wu = (R)(p.u_cost_weight > 0.0 ? p.u_cost_weight : 0.0);
-  a.wd = (R)(p.u_derivative_cost_weight > 0.0 ? p.u_derivative_cost_weight : 0.0);
-  // terminal rows in BuildProblem order (optimization.cc:236-267).  For the double pendulum (no optimizer
-  // in the reference) th_final / th_dot_final apply to both poles, both targets are upright.
-  a.term_is_cost = 0;
-  for (int t = 0; t < M::NX; ++t) {
-    double w, tgt;
-    if (t == 0) {
-      w = p.b_x_final_cost_weight;
-      tgt = 0.0;
-    } else if (t < M::NQ) {
-      w = p.th_final_cost_weight;
-      tgt = M_PI / 2;
-    } else if (t == M::NQ) {
-      w = p.b_x_dot_final_cost_weight;
-      tgt = 0.0;
-    } else {
-      w = p.th_dot_final_cost_weight;
-      tgt = 0.0;
-    }
-    const bool is_cost = w >= 0.0;
-    a.term_w[t] = (R)(is_cost ? w : 1.0);
-    a.term_tgt[t] = (R)tgt;
-    if (is_cost) a.term_is_cost |= (1 << t);
-  }
-  a.max_ls = o.max_line_search_iterations;
-  a.c1 = (R)o.armijo_c1;
-  a.shrink_max = (R)o.ls_shrink_max;
-  a.shrink_min = (R)o.ls_shrink_min;
-  a.alpha_growth = (R)o.ls_alpha_growth;
-  a.alpha_growth_bt = (R)o.ls_alpha_growth_backtracked;
-  a.full_step_below = (R)o.full_step_below;
-  a.rho = (R)o.penalty_rho;
-  a.lam_init = (R)o.lambda_initial;
-  a.lam_fail_init = (R)o.lambda_failure_init;
-  a.lam_up = (R)o.lambda_scale_up;
-  a.lam_down = (R)o.lambda_scale_down;
-  a.lam_min = (R)o.lambda_min;
-  a.lam_max = (R)o.lambda_max;
-  a.bx_lim = (R)o.b_x_limit;
-  a.u_lim = (R)o.u_limit;
-  a.rel_tol = (R)p.relative_exit_tol;
-  a.fo_tol = (R)p.absolute_first_derivative_tol;
-  a.mu_init = (R)p.equality_penalty_initial;
-  a.prev_B = s->prev_B;
-  using V4 = typename VecT<R>::V4;
-  using XVn = XV<R, M::NX>;
-  a.zx = (XVn*)s->zx;
-  a.zu = (R*)s->zu;
-  a.dzx = (XVn*)s->dzx;
-  a.dzu = (R*)s->dzu;
-  a.Phi = (XVn*)s->Phi;
-  a.Gam = (XVn*)s->Gam;
-  a.cs = (XVn*)s->cs;
-  a.Wk = (XVn*)s->Wk;
-  a.Tk = (V4*)s->Tk;
-  a.sc = (R*)s->sc;
-  a.ist = s->ist;
-  a.sin_table = (const R*)s->sin_table;
-}
-
-template <typename R, typename M>
-static void launch_linearize(const SolverArgs<R, M>& a, int SP, const XV<R, M::NX>* zx_in, const R* zu_in,
-                             const int32_t* status, hipStream_t stream) {
-  const dim3 grid = grid_for(a.B * (a.S - 1));
-#define CPMPC_LIN(SPV)                                                                                       \
-  case SPV:                                                                                                  \
-    hipLaunchKernelGGL((linearize_kernel<R, M, SPV>), grid, dim3(64), 0, stream, a, zx_in, zu_in, status);   \
-    break;
-  switch (SP) {
-    CPMPC_LIN(1)
-    CPMPC_LIN(2)
-    CPMPC_LIN(4)
-    CPMPC_LIN(5)
-    CPMPC_LIN(8)
-    CPMPC_LIN(10)
-    CPMPC_LIN(20)
-    default:  // no register-resident specialisation: run-time spacing, Gamma accumulated in the workspace
-      hipLaunchKernelGGL((linearize_dyn_kernel<R, M>), grid, dim3(64), 0, stream, a, zx_in, zu_in, status);
-      break;
-  }
-#undef CPMPC_LIN
-}
-
-// 1: the fp64 fused kernels also take batch-shared model constants from the kernel-argument segment (SGPRs).  Off by
-// default: see the note above launch_fused (tools/_build variant `shared64` measures it).
-#ifndef CPMPC_FUSED_SHARED_F64
-#define CPMPC_FUSED_SHARED_F64 0
-#endif
-
-// fused pipeline: compiled specialisations for these (L = S-1, SP) pairs ...
-static bool fused_static(int L, int SP) {  // the default horizon's spacings (N = 40) and N = 20
-  return (L == 4 && SP == 10) || (L == 8 && SP == 5) || (L == 2 && SP == 10) || (L == 4 && SP == 5) ||
-         (L == 2 && SP == 20) || (L == 5 && SP == 8) || (L == 10 && SP == 4);
-}
-// ... and a run-time-spacing variant (dynamic LDS) for any other spacing with one of these interval counts whose
-// per-wave LDS (80 scalars per lane and control for NX = 4) fits the 64 KB a dynamic allocation may take
-static size_t fused_dyn_bytes(const cpmpc_solver* s) {
-  const size_t xw = s->NX > 4 ? 8 : 4;
-  return (size_t)s->SP * 64 * (4 + xw) * s->esize;
-}
-static bool fused_dynamic(const cpmpc_solver* s) {
-  const int L = s->S - 1;
-  const bool l_ok = L == 2 || L == 4 || L == 5 || L == 8 || L == 10 || L == 16;
-  return l_ok && fused_dyn_bytes(s) <= 65536;
-}
-static bool fused_built(const cpmpc_solver* s) { return fused_static(s->S - 1, s->SP) || fused_dynamic(s); }
-static bool use_fused(const cpmpc_solver* s) {
-  if (s->pipeline == CPMPC_PIPELINE_SPLIT) return false;
-  if (!fused_built(s)) return false;
-  // AUTO: the 6-state model in fp64 needs 61 KB of LDS per wave in the fused kernel (2 waves per CU); the split
-  // pipeline is as fast there (measured 10.1 vs 9.7 M re-plans/s), so it stays the default for that case
-  if (s->pipeline == CPMPC_PIPELINE_AUTO && s->model == CPMPC_MODEL_DOUBLE && s->dtype == CPMPC_F64) return false;
-  return true;
-}
-
-// The shared-parameters specialisation (model constants wave-uniform, in SGPRs) is used in fp32 only: the fp64
-// kernel already sits at the SGPR limit with its VGPR/AGPR file exhausted, and with the constants added to the
-// scalar pressure hipcc 7.2 produced wrong results for it (caught by the fp64 parity tests); there the constants
-// go through load_consts() into vector registers like per-problem parameters do.
-template <typename R, typename M>
-static void launch_fused(const SolverArgs<R, M>& a, int L, int SP, int max_iters, hipStream_t stream) {
-  {
-    const int ppw = 64 / L;
-    const dim3 grid((unsigned)((a.B + ppw - 1) / ppw));
-#define CPMPC_FUSED(LV, SPV)                                                                                \
-  if (L == LV && SP == SPV) {                                                                               \
-    if constexpr (sizeof(R) == 4 || CPMPC_FUSED_SHARED_F64) {                                              \
-      if (a.dyn == nullptr) {                                                                               \
-        hipLaunchKernelGGL((fused_sqp_kernel<R, M, SPV, LV, true>), grid, dim3(64), 0, stream, a, max_iters); \
-        return;                                                                                             \
-      }                                                                                                     \
-    }                                                                                                       \
-    hipLaunchKernelGGL((fused_sqp_kernel<R, M, SPV, LV, false>), grid, dim3(64), 0, stream, a, max_iters);  \
-    return;                                                                                                 \
-  }
-    CPMPC_FUSED(4, 10)
-    CPMPC_FUSED(8, 5)
-    CPMPC_FUSED(2, 10)
-    CPMPC_FUSED(4, 5)
-    CPMPC_FUSED(2, 20)
-    CPMPC_FUSED(5, 8)
-    CPMPC_FUSED(10, 4)
-#undef CPMPC_FUSED
-    // no specialisation for this spacing: run-time SP, dynamic LDS
-    const size_t lds = fused_dyn_lds_bytes<R, M>(SP);
-#define CPMPC_FUSED_DYN(LV)                                                                                         \
-  if (L == LV) {                                                                                                    \
-    if constexpr (sizeof(R) == 4 || CPMPC_FUSED_SHARED_F64) {                                                      \
-      if (a.dyn == nullptr) {                                                                                       \
-        hipLaunchKernelGGL((fused_sqp_dyn_kernel<R, M, LV, true>), grid, dim3(64), lds, stream, a, max_iters);      \
-        return;                                                                                                     \
-      }                                                                                                             \
-    }                                                                                                               \
-    hipLaunchKernelGGL((fused_sqp_dyn_kernel<R, M, LV, false>), grid, dim3(64), lds, stream, a, max_iters);         \
-    return;                                                                                                         \
-  }
-    CPMPC_FUSED_DYN(2)
-    CPMPC_FUSED_DYN(4)
-    CPMPC_FUSED_DYN(5)
-    CPMPC_FUSED_DYN(8)
-    CPMPC_FUSED_DYN(10)
-    CPMPC_FUSED_DYN(16)
-#undef CPMPC_FUSED_DYN
-  }
-}
-
 extern "C" int cpmpc_set_pipeline(cpmpc_solver* s, int mode) {
   if (!s) return fail(CPMPC_ERR_INVALID_ARG, "null solver");
   if (mode != CPMPC_PIPELINE_AUTO && mode != CPMPC_PIPELINE_SPLIT && mode != CPMPC_PIPELINE_FUSED)
@@ -642,97 +384,6 @@ extern "C" int cpmpc_get_pipeline(const cpmpc_solver* s) {
   if (!s) return -1;
   return use_fused(s) ? CPMPC_PIPELINE_FUSED : CPMPC_PIPELINE_SPLIT;
 }
-
-template <typename R, typename M>
-static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* in, const cpmpc_step_outputs* out,
-                           hipStream_t stream) {
-  SolverArgs<R, M> a;
-  fill_args<R, M>(s, B, a);
-  a.x0 = (const R*)in->x0;
-  a.dyn = (const R*)in->dyn;
-  a.set_point = (const R*)in->set_point;
-  a.term_w_pp = (const R*)in->terminal_weights;
-  if (in->dyn == nullptr) a.consts = M::template make<double>(in->dyn_shared_host);
-  a.term_tgt[0] = (R)in->set_point_shared;
-  if (out) {
-    a.u_out = (R*)out->u;
-    a.pred_out = (R*)out->predicted;
-    a.status_out = out->status;
-    a.iters_out = out->iterations;
-    a.ls_out = out->ls_evals;
-    a.cost_out = (R*)out->final_cost;
-    a.eq_out = (R*)out->final_eq_l1;
-    a.guess_out = (R*)out->guess;
-    a.sol_out = (R*)out->solution;
-  }
-  const dim3 gridB = grid_for(B);
-  ProfSpan sp;
-
-  span_begin(s, CPMPC_KERNEL_PREPARE, stream, &sp);
-  hipLaunchKernelGGL((prepare_kernel<R, M>), dim3((unsigned)((B + CPMPC_PF_BLOCK - 1) / CPMPC_PF_BLOCK)), dim3(CPMPC_PF_BLOCK), 0, stream, a);
-  span_end(s, stream, &sp);
-
-  if (use_fused(s)) {
-    // With exit tolerances enabled problems stop after different numbers of iterations, and a wave lives as long
-    // as its slowest problem (closed loop, measured: 4.3 iterations per problem, 7.7 per wave of 16).  The kernel
-    // is restartable -- all solver state is in the workspace between launches -- so it runs in stages and the
-    // problems still iterating are compacted into dense waves in between.  Results are bitwise those of a single
-    // launch: a problem's arithmetic does not depend on the lanes it occupies.
-    const int total = (int)s->params.max_iterations;
-    const bool exits = s->params.relative_exit_tol > 0.0 || s->params.absolute_first_derivative_tol > 0.0;
-    bool staged = exits && s->stage_first > 0 && s->stage_next > 0 && total > s->stage_first;
-    // a batch that fits the machine in one round of resident waves (2 per SIMD) ends with its slowest wave either
-    // way: staging would only add launches
-    if (s->stage_auto && (B * (int64_t)(s->S - 1) + 63) / 64 <= 2048) staged = false;
-    if (s->active == nullptr) staged = false;  // no index list (allocation failed at creation): single launch, same results
-    a.active_list = nullptr;
-    a.active_count = nullptr;
-    a.iter_cap = total;
-    a.run_out_below = (int64_t)2048 * (64 / (s->S - 1));  // problems in one round of resident waves (2 per SIMD)
-    span_begin(s, CPMPC_KERNEL_FUSED, stream, &sp);
-    launch_fused<R, M>(a, s->S - 1, s->SP, staged ? s->stage_first : total, stream);
-    span_end(s, stream, &sp);
-    int stage = 0;
-    for (int done = s->stage_first; staged && done < total; done += s->stage_next, ++stage) {
-      int32_t* count = s->active + s->cap + (stage & 1);       // two counters: this compaction and the one before
-      a.prev_count = stage ? s->active + s->cap + ((stage - 1) & 1) : nullptr;
-      a.prev_total = B;
-      a.remaining = total - done;
-      span_begin(s, CPMPC_KERNEL_FUSED, stream, &sp);
-      const hipError_t memset_rc = hipMemsetAsync(count, 0, sizeof(int32_t), stream);
-      hipLaunchKernelGGL(compact_active_kernel, dim3((unsigned)((B + 1023) / 1024)), dim3(1024), 0, stream,
-                         (const int32_t*)(s->ist + (size_t)IS_STATUS * (size_t)s->cap),
-                         (const int32_t*)(s->ist + (size_t)IS_ITERS * (size_t)s->cap), total, B, s->active, count);
-      a.active_list = s->active;
-      a.active_count = count;
-      const int k = (total - done < s->stage_next) ? (total - done) : s->stage_next;
-      launch_fused<R, M>(a, s->S - 1, s->SP, k, stream);
-      span_end(s, stream, &sp);  // the span is closed (its events recycled) before any early return
-      if (memset_rc != hipSuccess) {
-        if (B > s->prev_B) s->prev_B = B;  // prepare has already shifted the warm start: keep the handle consistent
-        return fail(CPMPC_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(memset_rc));
-      }
-    }
-  } else {
-    for (int it = 0; it < (int)s->params.max_iterations; ++it) {
-      span_begin(s, CPMPC_KERNEL_LINEARIZE, stream, &sp);
-      launch_linearize<R, M>(a, s->SP, a.zx, a.zu, a.ist, stream);
-      span_end(s, stream, &sp);
-      span_begin(s, CPMPC_KERNEL_QP_LS, stream, &sp);
-      hipLaunchKernelGGL((qp_ls_kernel<R, M>), gridB, dim3(64), 0, stream, a);
-      span_end(s, stream, &sp);
-    }
-  }
-
-  span_begin(s, CPMPC_KERNEL_FINALIZE, stream, &sp);
-  hipLaunchKernelGGL((finalize_kernel<R, M>), dim3((unsigned)((B + CPMPC_PF_BLOCK - 1) / CPMPC_PF_BLOCK)), dim3(CPMPC_PF_BLOCK), 0, stream, a);
-  span_end(s, stream, &sp);
-
-  HIP_TRY(hipGetLastError());
-  if (B > s->prev_B) s->prev_B = B;  // previous_solution_ = solver_->variables()  (optimization.cc:85), per problem
-  return CPMPC_OK;
-}
-
 extern "C" int cpmpc_step_batch(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* in,
                                 const cpmpc_step_outputs* out, void* stream) {
   if (!s || !in) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
@@ -745,7 +396,7 @@ extern "C" int cpmpc_step_batch(cpmpc_solver* s, int64_t B, const cpmpc_step_inp
     return fail(CPMPC_ERR_INVALID_ARG, "set_point_shared must be finite");
   DeviceGuard guard(s->device);
   int rc = CPMPC_OK;
-  CPMPC_DISPATCH(s->dtype, s->model, (rc = step_batch_impl<R, M>(s, B, in, out, (hipStream_t)stream)));
+  rc = engine_of(s)->step_batch(s, B, in, out, (hipStream_t)stream);
   track_caller_stream(s, (hipStream_t)stream);
   return rc;
 }
@@ -758,9 +409,7 @@ extern "C" int cpmpc_set_previous_solution(cpmpc_solver* s, int64_t B, const voi
   if (B < 1 || B > s->cap) return fail(CPMPC_ERR_BATCH, "B out of range");
   DeviceGuard guard(s->device);
   // packed [dim][B] (MapKey order) -> workspace layout
-  CPMPC_DISPATCH(s->dtype, s->model,
-                 hipLaunchKernelGGL((pack_z_kernel<R, M::NX>), grid_for(B), dim3(64), 0, (hipStream_t)stream, B,
-                                    s->cap, s->S, s->N, (const R*)z, (XV<R, M::NX>*)s->zx, (R*)s->zu));
+  engine_of(s)->pack_z(s, B, z, (hipStream_t)stream);  // packed [dim][B] (MapKey order) -> workspace layout
   HIP_TRY(hipGetLastError());
   if (B > s->prev_B) s->prev_B = B;
   track_caller_stream(s, (hipStream_t)stream);
@@ -771,9 +420,7 @@ extern "C" int cpmpc_get_solution(cpmpc_solver* s, int64_t B, void* z_out, void*
   if (!s || !z_out) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
   if (B < 1 || B > s->cap) return fail(CPMPC_ERR_BATCH, "B out of range");
   DeviceGuard guard(s->device);
-  CPMPC_DISPATCH(s->dtype, s->model,
-                 hipLaunchKernelGGL((unpack_z_kernel<R, M::NX>), grid_for(B), dim3(64), 0, (hipStream_t)stream, B,
-                                    s->cap, s->S, s->N, (const XV<R, M::NX>*)s->zx, (const R*)s->zu, (R*)z_out));
+  engine_of(s)->unpack_z(s, B, z_out, (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   // this read of zx/zu on the caller's stream must finish before a later host-pointer call (on the handle's own
   // stream) overwrites them
@@ -784,7 +431,7 @@ extern "C" int cpmpc_get_solution(cpmpc_solver* s, int64_t B, void* z_out, void*
 // ------------------------------------------------------------------------------------------------
 // host-pointer convenience (staging copies around the same GPU path)
 // ------------------------------------------------------------------------------------------------
-static int ensure_stage(cpmpc_solver* s, size_t bytes) {
+int ensure_stage(cpmpc_solver* s, size_t bytes) {
   if (s->hstream == nullptr) {
     hipError_t e = hipStreamCreateWithFlags(&s->hstream, hipStreamNonBlocking);
     if (e != hipSuccess) return fail(CPMPC_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
@@ -816,116 +463,6 @@ static int ensure_stage(cpmpc_solver* s, size_t bytes) {
   return CPMPC_OK;
 }
 
-// A host-pointer step in two halves, so that several handles (the shards of cpmpc_sharded_*) can have their copies and
-// kernels in flight together: `begin` converts and uploads the inputs and queues the kernels and the copy back on the
-// handle's own stream; `end` waits for that stream and scatters the results into the caller's arrays.  The caller's
-// arrays are [field][ld] with this handle's B problems at columns [col0, col0 + B): ld = B, col0 = 0 for a plain call.
-struct HostStepLayout {
-  size_t off_u = 0, off_cost = 0, off_eq = 0, off_status = 0, off_iters = 0, off_sol = 0, off_pred = 0;  // bytes
-};
-
-template <typename R, typename M>
-static HostStepLayout host_step_layout(const cpmpc_solver* s, int64_t B) {
-  // staging layout, identical on the device and in the pinned mirror:
-  //   [x0 | u | cost | eq | status | iters | solution | predicted]      (the optional tails last: one copy back)
-  const size_t nB = (size_t)B;
-  HostStepLayout L;
-  L.off_u = (size_t)M::NX * nB * sizeof(R);
-  L.off_cost = L.off_u + (size_t)s->N * nB * sizeof(R);
-  L.off_eq = L.off_cost + nB * sizeof(R);
-  L.off_status = L.off_eq + nB * sizeof(R);
-  L.off_iters = L.off_status + nB * sizeof(int32_t);
-  L.off_sol = (L.off_iters + nB * sizeof(int32_t) + 7) & ~(size_t)7;  // the real-typed tail starts 8-byte aligned
-  L.off_pred = L.off_sol + (size_t)s->dim * nB * sizeof(R);
-  return L;
-}
-
-template <typename R, typename M>
-static int step_host_begin(cpmpc_solver* s, int64_t B, const double* x0_host, int64_t ld, int64_t col0,
-                           const double* dyn_shared_host, double set_point, bool want_pred, bool want_sol) {
-  const size_t nB = (size_t)B;
-  const size_t n_pred = (size_t)M::NX * (size_t)s->N * nB;
-  const HostStepLayout L = host_step_layout<R, M>(s, B);
-  const size_t bytes = L.off_pred + n_pred * sizeof(R) + 64;
-  int rc = ensure_stage(s, bytes);
-  if (rc) return rc;
-  char* d_base = (char*)s->stage;
-  R* d_x0 = (R*)d_base;
-  R* h_x0 = (R*)s->pin;
-  const hipStream_t st = s->hstream;
-  // from here on work is in flight on `st` that reads the pinned mirror and writes the staging buffer: every early
-  // return drains the stream first, so that the next call never reuses them under a running copy
-  auto bail = [&](int code) {
-    (void)hipStreamSynchronize(st);
-    return code;
-  };
-  for (int t = 0; t < M::NX; ++t) {
-    const double* src = x0_host + (size_t)t * (size_t)ld + (size_t)col0;
-    R* dst = h_x0 + (size_t)t * nB;
-    for (size_t i = 0; i < nB; ++i) dst[i] = (R)src[i];
-  }
-  hipError_t e = hipMemcpyAsync(d_x0, h_x0, L.off_u, hipMemcpyHostToDevice, st);
-  if (e != hipSuccess) return bail(fail(CPMPC_ERR_HIP, "hipMemcpyAsync (inputs) failed: %s", hipGetErrorString(e)));
-
-  cpmpc_step_inputs in;
-  memset(&in, 0, sizeof in);
-  in.x0 = d_x0;
-  in.dyn_shared_host = dyn_shared_host;
-  in.set_point_shared = set_point;
-  cpmpc_step_outputs out;
-  memset(&out, 0, sizeof out);
-  out.u = d_base + L.off_u;
-  out.predicted = want_pred ? d_base + L.off_pred : nullptr;
-  out.status = (int32_t*)(d_base + L.off_status);
-  out.iterations = (int32_t*)(d_base + L.off_iters);
-  out.final_cost = d_base + L.off_cost;
-  out.final_eq_l1 = d_base + L.off_eq;
-  out.solution = want_sol ? d_base + L.off_sol : nullptr;
-  rc = step_batch_impl<R, M>(s, B, &in, &out, st);
-  if (rc) return bail(rc);
-  // one copy back, from u to the end of what was asked for
-  const size_t end = want_pred ? L.off_pred + n_pred * sizeof(R)
-                               : (want_sol ? L.off_pred : L.off_iters + nB * sizeof(int32_t));
-  e = hipMemcpyAsync((char*)s->pin + L.off_u, d_base + L.off_u, end - L.off_u, hipMemcpyDeviceToHost, st);
-  if (e != hipSuccess) return bail(fail(CPMPC_ERR_HIP, "hipMemcpyAsync (outputs) failed: %s", hipGetErrorString(e)));
-  return CPMPC_OK;
-}
-
-template <typename R, typename M>
-static int step_host_end(cpmpc_solver* s, int64_t B, const cpmpc_step_host_outputs& ho, int64_t ld, int64_t col0) {
-  HIP_TRY(hipStreamSynchronize(s->hstream));
-  const size_t nB = (size_t)B;
-  const HostStepLayout L = host_step_layout<R, M>(s, B);
-  const char* h_base = (const char*)s->pin;
-  // rows of B scalars in the mirror -> rows of ld scalars in the caller's array, at column col0
-  auto fetch = [&](size_t off, double* hdst, size_t rows) {
-    if (!hdst) return;
-    const R* h = (const R*)(h_base + off);
-    for (size_t r = 0; r < rows; ++r) {
-      double* dst = hdst + r * (size_t)ld + (size_t)col0;
-      const R* src = h + r * nB;
-      for (size_t i = 0; i < nB; ++i) dst[i] = (double)src[i];
-    }
-  };
-  fetch(L.off_u, ho.u, (size_t)s->N);
-  fetch(L.off_cost, ho.final_cost, 1);
-  fetch(L.off_eq, ho.final_eq_l1, 1);
-  fetch(L.off_sol, ho.solution, (size_t)s->dim);
-  fetch(L.off_pred, ho.predicted, (size_t)M::NX * (size_t)s->N);
-  if (ho.status) memcpy(ho.status + col0, h_base + L.off_status, nB * sizeof(int32_t));
-  if (ho.iterations) memcpy(ho.iterations + col0, h_base + L.off_iters, nB * sizeof(int32_t));
-  return CPMPC_OK;
-}
-
-template <typename R, typename M>
-static int step_host_impl(cpmpc_solver* s, int64_t B, const double* x0_host, const double* dyn_shared_host,
-                          double set_point, const cpmpc_step_host_outputs& ho) {
-  const int rc = step_host_begin<R, M>(s, B, x0_host, B, 0, dyn_shared_host, set_point, ho.predicted != nullptr,
-                                       ho.solution != nullptr);
-  if (rc) return rc;
-  return step_host_end<R, M>(s, B, ho, B, 0);
-}
-
 extern "C" int cpmpc_step_batch_host_ex(cpmpc_solver* s, int64_t B, const double* x0_host,
                                         const double* dyn_shared_host, double set_point,
                                         const cpmpc_step_host_outputs* out) {
@@ -935,7 +472,9 @@ extern "C" int cpmpc_step_batch_host_ex(cpmpc_solver* s, int64_t B, const double
   if (!std::isfinite(set_point)) return fail(CPMPC_ERR_INVALID_ARG, "set_point must be finite");
   DeviceGuard guard(s->device);
   int rc = CPMPC_OK;
-  CPMPC_DISPATCH(s->dtype, s->model, (rc = step_host_impl<R, M>(s, B, x0_host, dyn_shared_host, set_point, *out)));
+  const Engine* e = engine_of(s);
+  rc = e->step_host_begin(s, B, x0_host, B, 0, dyn_shared_host, set_point, out->predicted != nullptr, out->solution != nullptr);
+  if (rc == CPMPC_OK) rc = e->step_host_end(s, B, *out, B, 0);
   return rc;
 }
 
@@ -1142,9 +681,8 @@ extern "C" int cpmpc_sharded_step_batch_host(cpmpc_sharded* s, int64_t B, const 
     if (hi == lo) continue;
     Shard& sh = s->shards[i];
     DeviceGuard guard(sh.device);
-    CPMPC_DISPATCH(sh.h->dtype, sh.h->model,
-                   (rc = step_host_begin<R, M>(sh.h, hi - lo, x0_host, B, lo, dyn_shared_host, set_point,
-                                               out->predicted != nullptr, out->solution != nullptr)));
+    rc = engine_of(sh.h)->step_host_begin(sh.h, hi - lo, x0_host, B, lo, dyn_shared_host, set_point,
+                                          out->predicted != nullptr, out->solution != nullptr);
     if (rc == CPMPC_OK) begun = i + 1;
   }
   int first_rc = rc;
@@ -1156,7 +694,7 @@ extern "C" int cpmpc_sharded_step_batch_host(cpmpc_sharded* s, int64_t B, const 
     DeviceGuard guard(sh.device);
     int rc_i = CPMPC_OK;
     if (first_rc == CPMPC_OK) {
-      CPMPC_DISPATCH(sh.h->dtype, sh.h->model, (rc_i = step_host_end<R, M>(sh.h, hi - lo, *out, B, lo)));
+      rc_i = engine_of(sh.h)->step_host_end(sh.h, hi - lo, *out, B, lo);
       if (rc_i != CPMPC_OK) first_rc = rc_i;
     } else {
       (void)hipStreamSynchronize(sh.h->hstream);
@@ -1262,17 +800,6 @@ static int current_device_ok() {
   return check_device(dev);
 }
 
-template <typename R>
-static ExtForce<R> ext_from_host(const double* fext_host) {
-  ExtForce<R> fe{R(0), R(0), R(0)};
-  if (fext_host) {
-    fe.fbx = (R)fext_host[0];
-    fe.fmx = (R)fext_host[2];
-    fe.fmy = (R)fext_host[3];
-  }
-  return fe;
-}
-
 static int check_piece_args(int model, int dtype, int64_t B) {
   if (model != CPMPC_MODEL_SINGLE && model != CPMPC_MODEL_DOUBLE) return fail(CPMPC_ERR_INVALID_ARG, "unknown model");
   if (dtype != CPMPC_F32 && dtype != CPMPC_F64) return fail(CPMPC_ERR_INVALID_ARG, "bad dtype");
@@ -1286,10 +813,7 @@ extern "C" int cpmpc_dynamics_batch_model(int model, int dtype, int64_t B, const
   if (!dyn_shared_host || !x || !u || !f) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
   int rc = check_piece_args(model, dtype, B);
   if (rc) return rc;
-  CPMPC_DISPATCH(dtype, model,
-                 hipLaunchKernelGGL((dynamics_kernel<R, M>), grid_for(B), dim3(64), 0, (hipStream_t)stream, B,
-                                    M::template make<double>(dyn_shared_host), ext_from_host<R>(fext_host),
-                                    (const R*)x, (const R*)u, (R*)f, (R*)Jx, (R*)Ju));
+  engine_for(dtype, model)->dynamics(B, dyn_shared_host, fext_host, x, u, f, Jx, Ju, (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return CPMPC_OK;
 }
@@ -1305,10 +829,7 @@ extern "C" int cpmpc_rk4_batch_model(int model, int dtype, int64_t B, const doub
   if (!dyn_shared_host || !x || !u || !x_new) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
   int rc = check_piece_args(model, dtype, B);
   if (rc) return rc;
-  CPMPC_DISPATCH(dtype, model,
-                 hipLaunchKernelGGL((rk4_kernel<R, M>), grid_for(B), dim3(64), 0, (hipStream_t)stream, B,
-                                    M::template make<double>(dyn_shared_host), ext_from_host<R>(fext_host), (R)h,
-                                    (const R*)x, (const R*)u, (R*)x_new, (R*)A, (R*)Bm));
+  engine_for(dtype, model)->rk4(B, dyn_shared_host, fext_host, h, x, u, x_new, A, Bm, (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return CPMPC_OK;
 }
@@ -1316,18 +837,6 @@ extern "C" int cpmpc_rk4_batch(int dtype, int64_t B, const double* dyn_shared_ho
                                double h, const double* fext_host, void* x_new, void* A, void* Bm, void* stream) {
   return cpmpc_rk4_batch_model(CPMPC_MODEL_SINGLE, dtype, B, dyn_shared_host, x, u, h, fext_host, x_new, A, Bm,
                                stream);
-}
-
-template <typename R, typename M>
-static void linearize_batch_impl(cpmpc_solver* s, int64_t B, const double* dyn_shared_host, const void* z, void* c,
-                                 void* Phi, void* Gamma, hipStream_t st) {
-  SolverArgs<R, M> a;
-  fill_args<R, M>(s, B, a);
-  a.consts = M::template make<double>(dyn_shared_host);
-  hipLaunchKernelGGL((pack_z_kernel<R, M::NX>), grid_for(B), dim3(64), 0, st, B, s->cap, s->S, s->N, (const R*)z,
-                     a.dzx, a.dzu);
-  launch_linearize<R, M>(a, s->SP, a.dzx, a.dzu, nullptr, st);
-  hipLaunchKernelGGL((unpack_lin_kernel<R, M>), grid_for(B), dim3(64), 0, st, a, (R*)c, (R*)Phi, (R*)Gamma);
 }
 
 extern "C" int cpmpc_linearize_batch(cpmpc_solver* s, int64_t B, const double* dyn_shared_host, const void* z,
@@ -1338,8 +847,7 @@ extern "C" int cpmpc_linearize_batch(cpmpc_solver* s, int64_t B, const double* d
   DeviceGuard guard(s->device);
   // the caller's z is packed into the step buffers (dzx/dzu), which hold no state between calls, so the
   // warm start (zx/zu) is untouched; the linearisation lands in the workspace and is unpacked
-  CPMPC_DISPATCH(s->dtype, s->model,
-                 (linearize_batch_impl<R, M>(s, B, dyn_shared_host, z, c, Phi, Gamma, (hipStream_t)stream)));
+  engine_of(s)->linearize_batch(s, B, dyn_shared_host, z, c, Phi, Gamma, (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   track_caller_stream(s, (hipStream_t)stream);  // the step buffers of the workspace were used on the caller's stream
   return CPMPC_OK;
@@ -1366,10 +874,7 @@ extern "C" int cpmpc_sim_step_batch_model(int model, int dtype, int64_t B, const
     }
   }
   if (n_sub == 0) return CPMPC_OK;
-  CPMPC_DISPATCH(dtype, model,
-                 hipLaunchKernelGGL((sim_kernel<R, M>), grid_for(B), dim3(64), 0, (hipStream_t)stream, B,
-                                    M::template make<double>(dyn_shared_host), ext_from_host<R>(fext_host),
-                                    (const R*)fext, n_sub, (R)h_last, (const R*)u, (R*)state));
+  engine_for(dtype, model)->sim(B, dyn_shared_host, fext_host, fext, n_sub, h_last, u, state, (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return CPMPC_OK;
 }
@@ -1448,27 +953,20 @@ extern "C" int cpmpc_sim_step_batch_host(int64_t B, const double* dyn_shared_hos
   return CPMPC_OK;
 }
 
+// debug builds only (-DCPMPC_FUSED_TIMING / -DCPMPC_FUSED_CLOCK): the counters of fused_sqp_kernel, summed over the
+// kernel translation units (each has its own copies), read and cleared
+static int debug_read_all(int which, unsigned long long* out, int n) {
+  (void)hipDeviceSynchronize();
+  for (int i = 0; i < n; ++i) out[i] = 0;
+  int ok = -1;
+  for (int dtype = 0; dtype < 2; ++dtype)
+    for (int model = 0; model < 2; ++model)
+      if (engine_for(dtype, model)->debug_read(which, out) == 0) ok = 0;
+  return ok;
+}
 #ifdef CPMPC_FUSED_TIMING
-// debug build only: read and clear the per-phase cycle counters of fused_sqp_kernel
-extern "C" int cpmpc_debug_phase_cycles(unsigned long long* out8) {
-  hipDeviceSynchronize();
-  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(cpmpc::g_fused_phase_cycles), 8 * sizeof(unsigned long long)) != hipSuccess)
-    return -1;
-  unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  hipMemcpyToSymbol(HIP_SYMBOL(cpmpc::g_fused_phase_cycles), zero, sizeof(zero));
-  return 0;
-}
+extern "C" int cpmpc_debug_phase_cycles(unsigned long long* out8) { return debug_read_all(0, out8, 8); }
 #endif
-
 #ifdef CPMPC_FUSED_CLOCK
-// debug build only: read and clear {sum of shader cycles, sum of 100 MHz ticks, waves, max cycles of a wave} of the
-// fused_sqp_kernel launches since the last call
-extern "C" int cpmpc_debug_kernel_clock(unsigned long long* out4) {
-  hipDeviceSynchronize();
-  if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(cpmpc::g_fused_clock), 4 * sizeof(unsigned long long)) != hipSuccess)
-    return -1;
-  unsigned long long zero[4] = {0, 0, 0, 0};
-  hipMemcpyToSymbol(HIP_SYMBOL(cpmpc::g_fused_clock), zero, sizeof(zero));
-  return 0;
-}
+extern "C" int cpmpc_debug_kernel_clock(unsigned long long* out4) { return debug_read_all(1, out4, 4); }
 #endif

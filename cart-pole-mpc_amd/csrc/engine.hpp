@@ -1,0 +1,140 @@
+// engine.hpp -- what the C-ABI translation unit (cpmpc_api.hip) and the four kernel translation units
+// (engine_<dtype>_<model>.hip) share: the solver handle, the error / profiling / staging helpers the API owns, and the
+// table of entry points through which the API reaches the kernels of one (dtype, model) pair.  The library is built
+// from five objects compiled in parallel; only the engine units contain device code.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "../../include/cpmpc.h"
+#include "workspace_layout.hpp"
+
+using namespace cpmpc;
+
+#define CPMPC_HIDDEN __attribute__((visibility("hidden")))
+
+// thread-local error text (cpmpc_last_error); returns `code`
+CPMPC_HIDDEN int cpmpc_fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+#define fail cpmpc_fail
+
+#define HIP_TRY(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return fail(CPMPC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),     \
+                  __FILE__, __LINE__);                                                      \
+  } while (0)
+
+struct ProfSpan {
+  int kernel;
+  hipEvent_t start, stop;
+};
+
+struct cpmpc_solver {
+  cpmpc_params params;
+  cpmpc_solver_opts opts;
+  int dtype;
+  int model;
+  int device;
+  int64_t cap;  // workspace stride (capacity rounded up to a multiple of 64)
+  int N, S, SP, NX, NP, dim;
+  size_t esize;
+  // one allocation, carved into fields
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+  char *zx, *zu, *dzx, *dzu, *Phi, *Gam, *cs, *Wk, *Tk, *sc;
+  int32_t* ist;
+  void* sin_table = nullptr;
+  int64_t prev_B = 0;  // problems [0, prev_B) hold a previous solution; Reset() -> 0
+  // staging for the *_host entry points (lazily allocated, grown on demand, owned by the handle): a device buffer,
+  // its pinned host mirror and a stream, so that a host-pointer call is one async copy in, the kernels, one async
+  // copy out and a single synchronisation
+  void* stage = nullptr;
+  void* pin = nullptr;
+  size_t stage_bytes = 0;
+  hipStream_t hstream = nullptr;
+  hipEvent_t ev_last = nullptr;  // end of the last device-pointer call on a caller's stream; hstream waits on it
+  bool ev_pending = false;
+  // profiling
+  int profiling = 0;
+  std::vector<ProfSpan> spans;
+  std::vector<ProfSpan> free_spans;
+  double prof_ms[CPMPC_KERNEL_COUNT] = {0, 0, 0, 0, 0};
+  int64_t prof_n[CPMPC_KERNEL_COUNT] = {0, 0, 0, 0, 0};
+  int pipeline = CPMPC_PIPELINE_AUTO;
+  // staged fused pipeline (compaction of the still-active problems between stages); 0/0 = single launch
+  int stage_first = 3, stage_next = 1;
+  bool stage_auto = true;  // default: stage only batches larger than one round of resident waves
+  int32_t* active = nullptr;  // [cap] compacted problem indices, then two counters
+};
+
+
+// owned by the API unit
+CPMPC_HIDDEN void span_begin(cpmpc_solver* s, int kernel, hipStream_t stream, ProfSpan* cur);
+CPMPC_HIDDEN void span_end(cpmpc_solver* s, hipStream_t stream, ProfSpan* cur);
+CPMPC_HIDDEN int ensure_stage(cpmpc_solver* s, size_t bytes);
+
+// fused pipeline: compiled specialisations for these (L = S-1, SP) pairs ...
+static inline bool fused_static(int L, int SP) {  // the default horizon's spacings (N = 40) and N = 20
+  return (L == 4 && SP == 10) || (L == 8 && SP == 5) || (L == 2 && SP == 10) || (L == 4 && SP == 5) ||
+         (L == 2 && SP == 20) || (L == 5 && SP == 8) || (L == 10 && SP == 4);
+}
+// ... and a run-time-spacing variant (dynamic LDS) for any other spacing with one of these interval counts whose
+// per-wave LDS (80 scalars per lane and control for NX = 4) fits the 64 KB a dynamic allocation may take
+static inline size_t fused_dyn_bytes(const cpmpc_solver* s) {
+  const size_t xw = s->NX > 4 ? 8 : 4;
+  return (size_t)s->SP * 64 * (4 + xw) * s->esize;
+}
+static inline bool fused_dynamic(const cpmpc_solver* s) {
+  const int L = s->S - 1;
+  const bool l_ok = L == 2 || L == 4 || L == 5 || L == 8 || L == 10 || L == 16;
+  return l_ok && fused_dyn_bytes(s) <= 65536;
+}
+static inline bool fused_built(const cpmpc_solver* s) { return fused_static(s->S - 1, s->SP) || fused_dynamic(s); }
+
+static inline bool use_fused(const cpmpc_solver* s) {
+  if (s->pipeline == CPMPC_PIPELINE_SPLIT) return false;
+  if (!fused_built(s)) return false;
+  // AUTO: the 6-state model in fp64 needs 61 KB of LDS per wave in the fused kernel (2 waves per CU); the split
+  // pipeline is as fast there (measured 10.1 vs 9.7 M re-plans/s), so it stays the default for that case
+  if (s->pipeline == CPMPC_PIPELINE_AUTO && s->model == CPMPC_MODEL_DOUBLE && s->dtype == CPMPC_F64) return false;
+  return true;
+}
+
+// Entry points of one (dtype, model) pair; every function launches the kernels of its own translation unit.
+struct Engine {
+  // Optimization::Step for B problems on `stream` (optimization.cc:39-97)
+  int (*step_batch)(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* in, const cpmpc_step_outputs* out,
+                    hipStream_t stream);
+  // a host-pointer step in two halves (upload + kernels + download queued; wait + scatter)
+  int (*step_host_begin)(cpmpc_solver* s, int64_t B, const double* x0_host, int64_t ld, int64_t col0,
+                         const double* dyn_shared_host, double set_point, bool want_pred, bool want_sol);
+  int (*step_host_end)(cpmpc_solver* s, int64_t B, const cpmpc_step_host_outputs& ho, int64_t ld, int64_t col0);
+  // packed z [dim][B] (MapKey order) <-> workspace
+  void (*pack_z)(cpmpc_solver* s, int64_t B, const void* z, hipStream_t stream);
+  void (*unpack_z)(cpmpc_solver* s, int64_t B, void* z_out, hipStream_t stream);
+  // stand-alone pieces
+  void (*dynamics)(int64_t B, const double* dyn_shared_host, const double* fext_host, const void* x, const void* u,
+                   void* f, void* Jx, void* Ju, hipStream_t stream);
+  void (*rk4)(int64_t B, const double* dyn_shared_host, const double* fext_host, double h, const void* x, const void* u,
+              void* x_new, void* A, void* Bm, hipStream_t stream);
+  void (*sim)(int64_t B, const double* dyn_shared_host, const double* fext_host, const void* fext, int n_sub,
+              double h_last, const void* u, void* state, hipStream_t stream);
+  void (*linearize_batch)(cpmpc_solver* s, int64_t B, const double* dyn_shared_host, const void* z, void* c, void* Phi,
+                          void* Gamma, hipStream_t stream);
+  // debug builds (-DCPMPC_FUSED_TIMING / -DCPMPC_FUSED_CLOCK): read and clear this unit's counters, ADDING them to out
+  // (which = 0: eight phase counters, 1: {cycles, 100 MHz ticks, waves, max cycles}); -1 when not built in
+  int (*debug_read)(int which, unsigned long long* out);
+};
+// (functions, not namespace-scope tables: hipcc would emit a constant table for the device side as well)
+CPMPC_HIDDEN const Engine* cpmpc_engine_f32_single();
+CPMPC_HIDDEN const Engine* cpmpc_engine_f64_single();
+CPMPC_HIDDEN const Engine* cpmpc_engine_f32_double();
+CPMPC_HIDDEN const Engine* cpmpc_engine_f64_double();
+static inline const Engine* engine_for(int dtype, int model) {
+  if (model == CPMPC_MODEL_SINGLE) return dtype == CPMPC_F32 ? cpmpc_engine_f32_single() : cpmpc_engine_f64_single();
+  return dtype == CPMPC_F32 ? cpmpc_engine_f32_double() : cpmpc_engine_f64_double();
+}
+static inline const Engine* engine_of(const cpmpc_solver* s) { return engine_for(s->dtype, s->model); }

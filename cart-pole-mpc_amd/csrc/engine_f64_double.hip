@@ -1,0 +1,5 @@
+// engine_f64_double.hip -- the kernels of one (dtype, model) pair and their host side (engine_impl.hpp), as one of the
+// library's translation units (compiled in parallel with the others, cart-pole-mpc_amd/build.py).
+#include "engine_impl.hpp"
+
+CPMPC_DEFINE_ENGINE(cpmpc_engine_f64_double, double, DoubleModel<double>)

@@ -1,0 +1,453 @@
+// engine_impl.hpp -- host side of the kernels of ONE (dtype, model) pair: argument set-up, launches, staging of the
+// host-pointer calls.  Included by engine_<dtype>_<model>.hip only, which instantiates everything for its pair and
+// exports it as an `Engine` table (engine.hpp); the C-ABI unit never sees device code.
+#pragma once
+#include <cmath>
+#include <cstring>
+
+#include "engine.hpp"
+#include "mpc_kernels.hpp"
+#include "mpc_fused.hpp"
+
+using namespace cpmpc;
+
+// ------------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------------
+static inline dim3 grid_for(int64_t threads) { return dim3((unsigned)((threads + 63) / 64)); }
+
+template <typename R, typename M>
+static void fill_args(const cpmpc_solver* s, int64_t B, SolverArgs<R, M>& a) {
+  const cpmpc_params& p = s->params;
+  const cpmpc_solver_opts& o = s->opts;
+  memset((void*)&a, 0, sizeof a);
+  a.B = B;
+  a.stride = s->cap;
+  a.N = s->N;
+  a.S = s->S;
+  a.SP = s->SP;
+  a.iter_cap = (int)p.max_iterations;
+  a.dt = (R)p.control_dt;
+  // rows exist only for strictly positive weights (optimization.cc:270,296)
+  a.wu = (R)(p.u_cost_weight > 0.0 ? p.u_cost_weight : 0.0);
+  a.wd = (R)(p.u_derivative_cost_weight > 0.0 ? p.u_derivative_cost_weight : 0.0);
+  // terminal rows in BuildProblem order (optimization.cc:236-267).  For the double pendulum (no optimizer
+  // in the reference) th_final / th_dot_final apply to both poles, both targets are upright.
+  a.term_is_cost = 0;
+  for (int t = 0; t < M::NX; ++t) {
+    double w, tgt;
+    if (t == 0) {
+      w = p.b_x_final_cost_weight;
+      tgt = 0.0;
+    } else if (t < M::NQ) {
+      w = p.th_final_cost_weight;
+      tgt = M_PI / 2;
+    } else if (t == M::NQ) {
+      w = p.b_x_dot_final_cost_weight;
+      tgt = 0.0;
+    } else {
+      w = p.th_dot_final_cost_weight;
+      tgt = 0.0;
+    }
+    const bool is_cost = w >= 0.0;
+    a.term_w[t] = (R)(is_cost ? w : 1.0);
+    a.term_tgt[t] = (R)tgt;
+    if (is_cost) a.term_is_cost |= (1 << t);
+  }
+  a.max_ls = o.max_line_search_iterations;
+  a.c1 = (R)o.armijo_c1;
+  a.shrink_max = (R)o.ls_shrink_max;
+  a.shrink_min = (R)o.ls_shrink_min;
+  a.alpha_growth = (R)o.ls_alpha_growth;
+  a.alpha_growth_bt = (R)o.ls_alpha_growth_backtracked;
+  a.full_step_below = (R)o.full_step_below;
+  a.rho = (R)o.penalty_rho;
+  a.lam_init = (R)o.lambda_initial;
+  a.lam_fail_init = (R)o.lambda_failure_init;
+  a.lam_up = (R)o.lambda_scale_up;
+  a.lam_down = (R)o.lambda_scale_down;
+  a.lam_min = (R)o.lambda_min;
+  a.lam_max = (R)o.lambda_max;
+  a.bx_lim = (R)o.b_x_limit;
+  a.u_lim = (R)o.u_limit;
+  a.rel_tol = (R)p.relative_exit_tol;
+  a.fo_tol = (R)p.absolute_first_derivative_tol;
+  a.mu_init = (R)p.equality_penalty_initial;
+  a.prev_B = s->prev_B;
+  using V4 = typename VecT<R>::V4;
+  using XVn = XV<R, M::NX>;
+  a.zx = (XVn*)s->zx;
+  a.zu = (R*)s->zu;
+  a.dzx = (XVn*)s->dzx;
+  a.dzu = (R*)s->dzu;
+  a.Phi = (XVn*)s->Phi;
+  a.Gam = (XVn*)s->Gam;
+  a.cs = (XVn*)s->cs;
+  a.Wk = (XVn*)s->Wk;
+  a.Tk = (V4*)s->Tk;
+  a.sc = (R*)s->sc;
+  a.ist = s->ist;
+  a.sin_table = (const R*)s->sin_table;
+}
+
+template <typename R, typename M>
+static void launch_linearize(const SolverArgs<R, M>& a, int SP, const XV<R, M::NX>* zx_in, const R* zu_in,
+                             const int32_t* status, hipStream_t stream) {
+  const dim3 grid = grid_for(a.B * (a.S - 1));
+#define CPMPC_LIN(SPV)                                                                                       \
+  case SPV:                                                                                                  \
+    hipLaunchKernelGGL((linearize_kernel<R, M, SPV>), grid, dim3(64), 0, stream, a, zx_in, zu_in, status);   \
+    break;
+  switch (SP) {
+    CPMPC_LIN(1)
+    CPMPC_LIN(2)
+    CPMPC_LIN(4)
+    CPMPC_LIN(5)
+    CPMPC_LIN(8)
+    CPMPC_LIN(10)
+    CPMPC_LIN(20)
+    default:  // no register-resident specialisation: run-time spacing, Gamma accumulated in the workspace
+      hipLaunchKernelGGL((linearize_dyn_kernel<R, M>), grid, dim3(64), 0, stream, a, zx_in, zu_in, status);
+      break;
+  }
+#undef CPMPC_LIN
+}
+
+// 1: the fp64 fused kernels also take batch-shared model constants from the kernel-argument segment (SGPRs).  Off by
+// default: see the note above launch_fused (tools/_build variant `shared64` measures it).
+#ifndef CPMPC_FUSED_SHARED_F64
+#define CPMPC_FUSED_SHARED_F64 0
+#endif
+
+// The shared-parameters specialisation (model constants wave-uniform, in SGPRs) is used in fp32 only: the fp64
+// kernel already sits at the SGPR limit with its VGPR/AGPR file exhausted, and with the constants added to the
+// scalar pressure hipcc 7.2 produced wrong results for it (caught by the fp64 parity tests); there the constants
+// go through load_consts() into vector registers like per-problem parameters do.
+template <typename R, typename M>
+static void launch_fused(const SolverArgs<R, M>& a, int L, int SP, int max_iters, hipStream_t stream) {
+  {
+    const int ppw = 64 / L;
+    const dim3 grid((unsigned)((a.B + ppw - 1) / ppw));
+#define CPMPC_FUSED(LV, SPV)                                                                                \
+  if (L == LV && SP == SPV) {                                                                               \
+    if constexpr (sizeof(R) == 4 || CPMPC_FUSED_SHARED_F64) {                                              \
+      if (a.dyn == nullptr) {                                                                               \
+        hipLaunchKernelGGL((fused_sqp_kernel<R, M, SPV, LV, true>), grid, dim3(64), 0, stream, a, max_iters); \
+        return;                                                                                             \
+      }                                                                                                     \
+    }                                                                                                       \
+    hipLaunchKernelGGL((fused_sqp_kernel<R, M, SPV, LV, false>), grid, dim3(64), 0, stream, a, max_iters);  \
+    return;                                                                                                 \
+  }
+    CPMPC_FUSED(4, 10)
+    CPMPC_FUSED(8, 5)
+    CPMPC_FUSED(2, 10)
+    CPMPC_FUSED(4, 5)
+    CPMPC_FUSED(2, 20)
+    CPMPC_FUSED(5, 8)
+    CPMPC_FUSED(10, 4)
+#undef CPMPC_FUSED
+    // no specialisation for this spacing: run-time SP, dynamic LDS
+    const size_t lds = fused_dyn_lds_bytes<R, M>(SP);
+#define CPMPC_FUSED_DYN(LV)                                                                                         \
+  if (L == LV) {                                                                                                    \
+    if constexpr (sizeof(R) == 4 || CPMPC_FUSED_SHARED_F64) {                                                      \
+      if (a.dyn == nullptr) {                                                                                       \
+        hipLaunchKernelGGL((fused_sqp_dyn_kernel<R, M, LV, true>), grid, dim3(64), lds, stream, a, max_iters); \
+        return;                                                                                                     \
+      }                                                                                                             \
+    }                                                                                                               \
+    hipLaunchKernelGGL((fused_sqp_dyn_kernel<R, M, LV, false>), grid, dim3(64), lds, stream, a, max_iters);  \
+    return;                                                                                                         \
+  }
+    CPMPC_FUSED_DYN(2)
+    CPMPC_FUSED_DYN(4)
+    CPMPC_FUSED_DYN(5)
+    CPMPC_FUSED_DYN(8)
+    CPMPC_FUSED_DYN(10)
+    CPMPC_FUSED_DYN(16)
+#undef CPMPC_FUSED_DYN
+  }
+}
+
+template <typename R, typename M>
+static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* in, const cpmpc_step_outputs* out,
+                           hipStream_t stream) {
+  SolverArgs<R, M> a;
+  fill_args<R, M>(s, B, a);
+  a.x0 = (const R*)in->x0;
+  a.dyn = (const R*)in->dyn;
+  a.set_point = (const R*)in->set_point;
+  a.term_w_pp = (const R*)in->terminal_weights;
+  if (in->dyn == nullptr) a.consts = M::template make<double>(in->dyn_shared_host);
+  a.term_tgt[0] = (R)in->set_point_shared;
+  if (out) {
+    a.u_out = (R*)out->u;
+    a.pred_out = (R*)out->predicted;
+    a.status_out = out->status;
+    a.iters_out = out->iterations;
+    a.ls_out = out->ls_evals;
+    a.cost_out = (R*)out->final_cost;
+    a.eq_out = (R*)out->final_eq_l1;
+    a.guess_out = (R*)out->guess;
+    a.sol_out = (R*)out->solution;
+  }
+  const dim3 gridB = grid_for(B);
+  ProfSpan sp;
+
+  span_begin(s, CPMPC_KERNEL_PREPARE, stream, &sp);
+  hipLaunchKernelGGL((prepare_kernel<R, M>), dim3((unsigned)((B + CPMPC_PF_BLOCK - 1) / CPMPC_PF_BLOCK)), dim3(CPMPC_PF_BLOCK), 0, stream, a);
+  span_end(s, stream, &sp);
+
+  if (use_fused(s)) {
+    // With exit tolerances enabled problems stop after different numbers of iterations, and a wave lives as long
+    // as its slowest problem (closed loop, measured: 4.3 iterations per problem, 7.7 per wave of 16).  The kernel
+    // is restartable -- all solver state is in the workspace between launches -- so it runs in stages and the
+    // problems still iterating are compacted into dense waves in between.  Results are bitwise those of a single
+    // launch: a problem's arithmetic does not depend on the lanes it occupies.
+    const int total = (int)s->params.max_iterations;
+    const bool exits = s->params.relative_exit_tol > 0.0 || s->params.absolute_first_derivative_tol > 0.0;
+    bool staged = exits && s->stage_first > 0 && s->stage_next > 0 && total > s->stage_first;
+    // a batch that fits the machine in one round of resident waves (2 per SIMD) ends with its slowest wave either
+    // way: staging would only add launches
+    if (s->stage_auto && (B * (int64_t)(s->S - 1) + 63) / 64 <= 2048) staged = false;
+    if (s->active == nullptr) staged = false;  // no index list (allocation failed at creation): single launch, same results
+    a.active_list = nullptr;
+    a.active_count = nullptr;
+    a.iter_cap = total;
+    a.run_out_below = (int64_t)2048 * (64 / (s->S - 1));  // problems in one round of resident waves (2 per SIMD)
+    span_begin(s, CPMPC_KERNEL_FUSED, stream, &sp);
+    launch_fused<R, M>(a, s->S - 1, s->SP, staged ? s->stage_first : total, stream);
+    span_end(s, stream, &sp);
+    int stage = 0;
+    for (int done = s->stage_first; staged && done < total; done += s->stage_next, ++stage) {
+      int32_t* count = s->active + s->cap + (stage & 1);       // two counters: this compaction and the one before
+      a.prev_count = stage ? s->active + s->cap + ((stage - 1) & 1) : nullptr;
+      a.prev_total = B;
+      a.remaining = total - done;
+      span_begin(s, CPMPC_KERNEL_FUSED, stream, &sp);
+      const hipError_t memset_rc = hipMemsetAsync(count, 0, sizeof(int32_t), stream);
+      hipLaunchKernelGGL((compact_active_kernel<M>), dim3((unsigned)((B + 1023) / 1024)), dim3(1024), 0, stream,
+                         (const int32_t*)(s->ist + (size_t)IS_STATUS * (size_t)s->cap),
+                         (const int32_t*)(s->ist + (size_t)IS_ITERS * (size_t)s->cap), total, B, s->active, count);
+      a.active_list = s->active;
+      a.active_count = count;
+      const int k = (total - done < s->stage_next) ? (total - done) : s->stage_next;
+      launch_fused<R, M>(a, s->S - 1, s->SP, k, stream);
+      span_end(s, stream, &sp);  // the span is closed (its events recycled) before any early return
+      if (memset_rc != hipSuccess) {
+        if (B > s->prev_B) s->prev_B = B;  // prepare has already shifted the warm start: keep the handle consistent
+        return fail(CPMPC_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(memset_rc));
+      }
+    }
+  } else {
+    for (int it = 0; it < (int)s->params.max_iterations; ++it) {
+      span_begin(s, CPMPC_KERNEL_LINEARIZE, stream, &sp);
+      launch_linearize<R, M>(a, s->SP, a.zx, a.zu, a.ist, stream);
+      span_end(s, stream, &sp);
+      span_begin(s, CPMPC_KERNEL_QP_LS, stream, &sp);
+      hipLaunchKernelGGL((qp_ls_kernel<R, M>), gridB, dim3(64), 0, stream, a);
+      span_end(s, stream, &sp);
+    }
+  }
+
+  span_begin(s, CPMPC_KERNEL_FINALIZE, stream, &sp);
+  hipLaunchKernelGGL((finalize_kernel<R, M>), dim3((unsigned)((B + CPMPC_PF_BLOCK - 1) / CPMPC_PF_BLOCK)), dim3(CPMPC_PF_BLOCK), 0, stream, a);
+  span_end(s, stream, &sp);
+
+  HIP_TRY(hipGetLastError());
+  if (B > s->prev_B) s->prev_B = B;  // previous_solution_ = solver_->variables()  (optimization.cc:85), per problem
+  return CPMPC_OK;
+}
+
+// A host-pointer step in two halves, so that several handles (the shards of cpmpc_sharded_*) can have their copies and
+// kernels in flight together: `begin` converts and uploads the inputs and queues the kernels and the copy back on the
+// handle's own stream; `end` waits for that stream and scatters the results into the caller's arrays.  The caller's
+// arrays are [field][ld] with this handle's B problems at columns [col0, col0 + B): ld = B, col0 = 0 for a plain call.
+struct HostStepLayout {
+  size_t off_u = 0, off_cost = 0, off_eq = 0, off_status = 0, off_iters = 0, off_sol = 0, off_pred = 0;  // bytes
+};
+
+template <typename R, typename M>
+static HostStepLayout host_step_layout(const cpmpc_solver* s, int64_t B) {
+  // staging layout, identical on the device and in the pinned mirror:
+  //   [x0 | u | cost | eq | status | iters | solution | predicted]      (the optional tails last: one copy back)
+  const size_t nB = (size_t)B;
+  HostStepLayout L;
+  L.off_u = (size_t)M::NX * nB * sizeof(R);
+  L.off_cost = L.off_u + (size_t)s->N * nB * sizeof(R);
+  L.off_eq = L.off_cost + nB * sizeof(R);
+  L.off_status = L.off_eq + nB * sizeof(R);
+  L.off_iters = L.off_status + nB * sizeof(int32_t);
+  L.off_sol = (L.off_iters + nB * sizeof(int32_t) + 7) & ~(size_t)7;  // the real-typed tail starts 8-byte aligned
+  L.off_pred = L.off_sol + (size_t)s->dim * nB * sizeof(R);
+  return L;
+}
+
+template <typename R, typename M>
+static int step_host_begin(cpmpc_solver* s, int64_t B, const double* x0_host, int64_t ld, int64_t col0,
+                           const double* dyn_shared_host, double set_point, bool want_pred, bool want_sol) {
+  const size_t nB = (size_t)B;
+  const size_t n_pred = (size_t)M::NX * (size_t)s->N * nB;
+  const HostStepLayout L = host_step_layout<R, M>(s, B);
+  const size_t bytes = L.off_pred + n_pred * sizeof(R) + 64;
+  int rc = ensure_stage(s, bytes);
+  if (rc) return rc;
+  char* d_base = (char*)s->stage;
+  R* d_x0 = (R*)d_base;
+  R* h_x0 = (R*)s->pin;
+  const hipStream_t st = s->hstream;
+  // from here on work is in flight on `st` that reads the pinned mirror and writes the staging buffer: every early
+  // return drains the stream first, so that the next call never reuses them under a running copy
+  auto bail = [&](int code) {
+    (void)hipStreamSynchronize(st);
+    return code;
+  };
+  for (int t = 0; t < M::NX; ++t) {
+    const double* src = x0_host + (size_t)t * (size_t)ld + (size_t)col0;
+    R* dst = h_x0 + (size_t)t * nB;
+    for (size_t i = 0; i < nB; ++i) dst[i] = (R)src[i];
+  }
+  hipError_t e = hipMemcpyAsync(d_x0, h_x0, L.off_u, hipMemcpyHostToDevice, st);
+  if (e != hipSuccess) return bail(fail(CPMPC_ERR_HIP, "hipMemcpyAsync (inputs) failed: %s", hipGetErrorString(e)));
+
+  cpmpc_step_inputs in;
+  memset(&in, 0, sizeof in);
+  in.x0 = d_x0;
+  in.dyn_shared_host = dyn_shared_host;
+  in.set_point_shared = set_point;
+  cpmpc_step_outputs out;
+  memset(&out, 0, sizeof out);
+  out.u = d_base + L.off_u;
+  out.predicted = want_pred ? d_base + L.off_pred : nullptr;
+  out.status = (int32_t*)(d_base + L.off_status);
+  out.iterations = (int32_t*)(d_base + L.off_iters);
+  out.final_cost = d_base + L.off_cost;
+  out.final_eq_l1 = d_base + L.off_eq;
+  out.solution = want_sol ? d_base + L.off_sol : nullptr;
+  rc = step_batch_impl<R, M>(s, B, &in, &out, st);
+  if (rc) return bail(rc);
+  // one copy back, from u to the end of what was asked for
+  const size_t end = want_pred ? L.off_pred + n_pred * sizeof(R)
+                               : (want_sol ? L.off_pred : L.off_iters + nB * sizeof(int32_t));
+  e = hipMemcpyAsync((char*)s->pin + L.off_u, d_base + L.off_u, end - L.off_u, hipMemcpyDeviceToHost, st);
+  if (e != hipSuccess) return bail(fail(CPMPC_ERR_HIP, "hipMemcpyAsync (outputs) failed: %s", hipGetErrorString(e)));
+  return CPMPC_OK;
+}
+
+template <typename R, typename M>
+static int step_host_end(cpmpc_solver* s, int64_t B, const cpmpc_step_host_outputs& ho, int64_t ld, int64_t col0) {
+  HIP_TRY(hipStreamSynchronize(s->hstream));
+  const size_t nB = (size_t)B;
+  const HostStepLayout L = host_step_layout<R, M>(s, B);
+  const char* h_base = (const char*)s->pin;
+  // rows of B scalars in the mirror -> rows of ld scalars in the caller's array, at column col0
+  auto fetch = [&](size_t off, double* hdst, size_t rows) {
+    if (!hdst) return;
+    const R* h = (const R*)(h_base + off);
+    for (size_t r = 0; r < rows; ++r) {
+      double* dst = hdst + r * (size_t)ld + (size_t)col0;
+      const R* src = h + r * nB;
+      for (size_t i = 0; i < nB; ++i) dst[i] = (double)src[i];
+    }
+  };
+  fetch(L.off_u, ho.u, (size_t)s->N);
+  fetch(L.off_cost, ho.final_cost, 1);
+  fetch(L.off_eq, ho.final_eq_l1, 1);
+  fetch(L.off_sol, ho.solution, (size_t)s->dim);
+  fetch(L.off_pred, ho.predicted, (size_t)M::NX * (size_t)s->N);
+  if (ho.status) memcpy(ho.status + col0, h_base + L.off_status, nB * sizeof(int32_t));
+  if (ho.iterations) memcpy(ho.iterations + col0, h_base + L.off_iters, nB * sizeof(int32_t));
+  return CPMPC_OK;
+}
+
+template <typename R>
+static ExtForce<R> ext_from_host(const double* fext_host) {
+  ExtForce<R> fe{R(0), R(0), R(0)};
+  if (fext_host) {
+    fe.fbx = (R)fext_host[0];
+    fe.fmx = (R)fext_host[2];
+    fe.fmy = (R)fext_host[3];
+  }
+  return fe;
+}
+
+template <typename R, typename M>
+static void linearize_batch_impl(cpmpc_solver* s, int64_t B, const double* dyn_shared_host, const void* z, void* c,
+                                 void* Phi, void* Gamma, hipStream_t st) {
+  SolverArgs<R, M> a;
+  fill_args<R, M>(s, B, a);
+  a.consts = M::template make<double>(dyn_shared_host);
+  hipLaunchKernelGGL((pack_z_kernel<R, M::NX>), grid_for(B), dim3(64), 0, st, B, s->cap, s->S, s->N, (const R*)z,
+                     a.dzx, a.dzu);
+  launch_linearize<R, M>(a, s->SP, a.dzx, a.dzu, nullptr, st);
+  hipLaunchKernelGGL((unpack_lin_kernel<R, M>), grid_for(B), dim3(64), 0, st, a, (R*)c, (R*)Phi, (R*)Gamma);
+}
+
+
+// ---- the remaining entry points of the table ----------------------------------------------------------------------
+template <typename R, typename M>
+static void pack_z_impl(cpmpc_solver* s, int64_t B, const void* z, hipStream_t stream) {
+  hipLaunchKernelGGL((pack_z_kernel<R, M::NX>), grid_for(B), dim3(64), 0, stream, B, s->cap, s->S, s->N, (const R*)z,
+                     (XV<R, M::NX>*)s->zx, (R*)s->zu);
+}
+template <typename R, typename M>
+static void unpack_z_impl(cpmpc_solver* s, int64_t B, void* z_out, hipStream_t stream) {
+  hipLaunchKernelGGL((unpack_z_kernel<R, M::NX>), grid_for(B), dim3(64), 0, stream, B, s->cap, s->S, s->N,
+                     (const XV<R, M::NX>*)s->zx, (const R*)s->zu, (R*)z_out);
+}
+template <typename R, typename M>
+static void dynamics_impl(int64_t B, const double* dyn_shared_host, const double* fext_host, const void* x, const void* u,
+                          void* f, void* Jx, void* Ju, hipStream_t stream) {
+  hipLaunchKernelGGL((dynamics_kernel<R, M>), grid_for(B), dim3(64), 0, stream, B,
+                     M::template make<double>(dyn_shared_host), ext_from_host<R>(fext_host), (const R*)x, (const R*)u,
+                     (R*)f, (R*)Jx, (R*)Ju);
+}
+template <typename R, typename M>
+static void rk4_impl(int64_t B, const double* dyn_shared_host, const double* fext_host, double h, const void* x,
+                     const void* u, void* x_new, void* A, void* Bm, hipStream_t stream) {
+  hipLaunchKernelGGL((rk4_kernel<R, M>), grid_for(B), dim3(64), 0, stream, B, M::template make<double>(dyn_shared_host),
+                     ext_from_host<R>(fext_host), (R)h, (const R*)x, (const R*)u, (R*)x_new, (R*)A, (R*)Bm);
+}
+template <typename R, typename M>
+static void sim_impl(int64_t B, const double* dyn_shared_host, const double* fext_host, const void* fext, int n_sub,
+                     double h_last, const void* u, void* state, hipStream_t stream) {
+  hipLaunchKernelGGL((sim_kernel<R, M>), grid_for(B), dim3(64), 0, stream, B, M::template make<double>(dyn_shared_host),
+                     ext_from_host<R>(fext_host), (const R*)fext, n_sub, (R)h_last, (const R*)u, (R*)state);
+}
+
+// debug builds: this unit's copies of the counters (every translation unit has its own __device__ variables)
+static int debug_read_impl(int which, unsigned long long* out) {
+#ifdef CPMPC_FUSED_TIMING
+  if (which == 0) {
+    unsigned long long v[8], zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(v, HIP_SYMBOL(cpmpc::g_fused_phase_cycles), sizeof v) != hipSuccess) return -1;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(cpmpc::g_fused_phase_cycles), zero, sizeof zero);
+    for (int i = 0; i < 8; ++i) out[i] += v[i];
+    return 0;
+  }
+#endif
+#ifdef CPMPC_FUSED_CLOCK
+  if (which == 1) {
+    unsigned long long v[4], zero[4] = {0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(v, HIP_SYMBOL(cpmpc::g_fused_clock), sizeof v) != hipSuccess) return -1;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(cpmpc::g_fused_clock), zero, sizeof zero);
+    out[0] += v[0];
+    out[1] += v[1];
+    out[2] += v[2];
+    if (v[3] > out[3]) out[3] = v[3];
+    return 0;
+  }
+#endif
+  (void)which;
+  (void)out;
+  return -1;
+}
+
+#define CPMPC_DEFINE_ENGINE(NAME, R, M)                                                                              \
+  const Engine* NAME() {                                                                                             \
+    static const Engine e = {&step_batch_impl<R, M>, &step_host_begin<R, M>, &step_host_end<R, M>, &pack_z_impl<R, M>, \
+                             &unpack_z_impl<R, M>,   &dynamics_impl<R, M>,   &rk4_impl<R, M>,      &sim_impl<R, M>,    \
+                             &linearize_batch_impl<R, M>, &debug_read_impl};                                         \
+    return &e;                                                                                                       \
+  }

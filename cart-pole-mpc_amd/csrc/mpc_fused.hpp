@@ -176,6 +176,10 @@ __device__ __forceinline__ R group_last(R v, int gbase) {
 #ifndef CPMPC_FUSED_REFINE_F32
 #define CPMPC_FUSED_REFINE_F32 1
 #endif
+// refinement passes in a float kernel whose terminal system is carried in double (wide.hpp; measured in round 4)
+#ifndef CPMPC_FUSED_REFINE_WIDE
+#define CPMPC_FUSED_REFINE_WIDE 0
+#endif
 // refinement passes of the terminal multipliers for horizons of more than four intervals (fp64)
 #ifndef CPMPC_FUSED_REFINE_LONG
 #define CPMPC_FUSED_REFINE_LONG 2
@@ -199,7 +203,7 @@ __device__ __forceinline__ R group_last(R v, int gbase) {
 // Debug build only (-DCPMPC_FUSED_TIMING): shader-clock cycles per phase, summed over waves, read back by
 // cpmpc_debug_phase_cycles().  Not part of the product library.
 #ifdef CPMPC_FUSED_TIMING
-__device__ unsigned long long g_fused_phase_cycles[8];
+static __device__ unsigned long long g_fused_phase_cycles[8];  // one copy per translation unit
 #define CPMPC_TICK_INIT() unsigned long long tick_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tick_last = __builtin_readcyclecounter()
 #define CPMPC_TICK(IDX)                                              \
   do {                                                               \
@@ -224,7 +228,7 @@ __device__ unsigned long long g_fused_phase_cycles[8];
 // kernel runs (MI355X_MICROARCH.md, DVFS give-back item 6).  The stamps go to a buffer of their own that nothing else
 // reads; read back by cpmpc_debug_kernel_clock().  Not part of the product library.
 #ifdef CPMPC_FUSED_CLOCK
-__device__ unsigned long long g_fused_clock[4];  // sum of shader cycles, sum of 100 MHz ticks, waves, max cycles
+static __device__ unsigned long long g_fused_clock[4];  // sum of shader cycles, sum of 100 MHz ticks, waves, max cycles
 #define CPMPC_CLOCK_BEGIN()                                                  \
   const unsigned long long clk_c0 = __builtin_amdgcn_s_memtime();           \
   const unsigned long long clk_r0 = __builtin_amdgcn_s_memrealtime()

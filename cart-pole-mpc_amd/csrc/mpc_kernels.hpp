@@ -22,6 +22,8 @@
 #include <stdint.h>
 
 #include "models.hpp"
+#include "wide.hpp"
+#include "workspace_layout.hpp"
 
 // threads per workgroup of the one-thread-per-problem kernels before and after the SQP (prepare, finalize)
 #ifndef CPMPC_PF_BLOCK
@@ -37,13 +39,6 @@ constexpr int kTermFirstOrder = 4;
 constexpr int kTermQpIndefinite = 5;
 constexpr int kTermMaxLambda = 7;
 constexpr int kTermNonFinite = 8;
-
-// per-problem real scalars kept in the workspace (index into `sc`)
-// SC_TRIAL: 1 when SC_F_LAST / SC_CN_LAST are the merit pieces of the CURRENT iterate as the line search evaluated
-// them (the accepted trial point IS the new iterate, bit for bit), 0 when no trial has been accepted yet
-enum { SC_LAMBDA = 0, SC_MU, SC_F_LAST, SC_CN_LAST, SC_UPREV, SC_ALPHA, SC_TRIAL, SC_COUNT };
-// per-problem int scalars (index into `ist`)
-enum { IS_STATUS = 0, IS_ITERS, IS_LS_EVALS, IS_FAILED, IS_COUNT };
 
 constexpr int kMaxNX = 6;
 
@@ -211,6 +206,13 @@ __device__ __forceinline__ R nan_max(R a, R b) {
   return (sizeof(R) == 8) ? (R)__builtin_fmax((double)a, (double)b) : (R)__builtin_fmaxf((float)a, (float)b);
 }
 
+// reciprocal of a pivot of the terminal system in its wide type W; W == R keeps the kernel's own division
+template <typename R, typename W>
+__device__ __forceinline__ W wide_inv(const W d) {
+  if constexpr (std::is_same<W, R>::value) return Math<R>::div(R(1), d);
+  else return Math<double>::div(1.0, d);
+}
+
 // wrap the pole angles of a state / state difference
 template <typename R, typename M>
 __device__ __forceinline__ void wrap_angles(R (&x)[M::NX]) {
@@ -227,6 +229,7 @@ __device__ __forceinline__ void wrap_angles(R (&x)[M::NX]) {
 // waves kept alive by one straggler.  One atomic per wave (ballot + prefix popcount); the order of the
 // list is arbitrary, which is harmless: a problem's arithmetic does not depend on where it sits.
 // ------------------------------------------------------------------------------------------------
+template <typename Tag>  // Tag = the model policy: one instance per translation unit of the library (engine_*.hip)
 __global__ __launch_bounds__(1024) void compact_active_kernel(const int32_t* status, const int32_t* iters,
                                                               int iter_cap, int64_t B, int32_t* list, int32_t* count) {
   // one atomic per 1024-thread workgroup (16 waves): the wave totals go through LDS, wave 0 reserves the block's range.
@@ -587,10 +590,15 @@ __device__ __forceinline__ void merit_eval(const SolverArgs<R, M>& a, const type
 // Then the l1-merit penalty update and the Armijo line search with quadratic-interpolation
 // backtracking, started from the remembered step length.
 // ------------------------------------------------------------------------------------------------
+// The terminal system (S, rho, the weighted free response, the LDL^T and its solve) is carried in the wide type W of
+// wide.hpp: double in a float kernel, R itself in a double kernel.
 template <typename R, typename M>
 __global__ CPMPC_QPLS_BOUNDS void qp_ls_kernel(const SolverArgs<R, M> a) {
   using V4 = typename VecT<R>::V4;
   using XVn = XV<R, M::NX>;
+  using W = typename WideOf<R>::type;
+  using WO = Wide<W>;
+  constexpr bool kWidened = !std::is_same<W, R>::value;
   constexpr int NX = M::NX;
   const unsigned p = blockIdx.x * 64u + threadIdx.x;
   if (p >= a.B) return;
@@ -627,7 +635,8 @@ __global__ CPMPC_QPLS_BOUNDS void qp_ls_kernel(const SolverArgs<R, M> a) {
   }
   // The weighted free response  ha = diag(w) dx_{S-1}|_{du=0} = sum_s Psi_s c_s - Psi_{-1} c_init  is
   // accumulated inside sweep 1, where Psi_s = diag(w) Phi_{S-2}...Phi_{s+1} is available anyway.
-  R hv[NX], Rw[NX], Dg[NX], e_term[NX];
+  W hv[NX];
+  R Rw[NX], Dg[NX], e_term[NX];
   {
     R zt[NX];
     unpack<R, NX>(a.zx[(int64_t)(S - 1) * st + p], zt);
@@ -644,17 +653,17 @@ __global__ CPMPC_QPLS_BOUNDS void qp_ls_kernel(const SolverArgs<R, M> a) {
       } else {
         cn += Math<R>::fabs(e_term[t]);
       }
-      hv[t] = Rw[t] * e_term[t];  // + ha[t], added after sweep 1
+      hv[t] = WO::prod(Rw[t], e_term[t]);  // + ha[t], added after sweep 1
     }
   }
 
   // ---- sweep 1 (k descending) -------------------------------------------------------------------
-  R Sm[NX][NX], rho[NX];
+  W Sm[NX][NX], rho[NX];
 #pragma unroll
   for (int i = 0; i < NX; ++i) {
-    rho[i] = R(0);
+    rho[i] = WO::of(R(0));
 #pragma unroll
-    for (int j = 0; j < NX; ++j) Sm[i][j] = R(0);
+    for (int j = 0; j < NX; ++j) Sm[i][j] = WO::of(R(0));
   }
   bool pd_ok = true;
   {
@@ -663,11 +672,12 @@ __global__ CPMPC_QPLS_BOUNDS void qp_ls_kernel(const SolverArgs<R, M> a) {
     for (int r = 0; r < NX; ++r)
 #pragma unroll
       for (int c = 0; c < NX; ++c) Psi[r][c] = (r == c) ? Rw[r] : R(0);
-    R wprev[NX], ha[NX];
+    R wprev[NX];
+    W ha[NX];
 #pragma unroll
     for (int r = 0; r < NX; ++r) {
       wprev[r] = R(0);
-      ha[r] = R(0);
+      ha[r] = WO::of(R(0));
     }
     R gwprev = R(0);
     R d_next = R(1);
@@ -715,7 +725,7 @@ __global__ CPMPC_QPLS_BOUNDS void qp_ls_kernel(const SolverArgs<R, M> a) {
         a.Tk[(int64_t)kk * st + p] = mk4<R>(gw, ups, inv_d, g);
 #pragma unroll
         for (int i2 = 0; i2 < NX; ++i2) {
-          const R wi = wk[i2] * inv_d;
+          const W wi = WO::prod(wk[i2], inv_d);  // exact in W: S is the Gram matrix of the rounded rows (wide.hpp)
           rho[i2] += wi * gw;
 #pragma unroll
           for (int j2 = 0; j2 <= i2; ++j2) Sm[i2][j2] += wi * wk[j2];
@@ -734,9 +744,9 @@ __global__ CPMPC_QPLS_BOUNDS void qp_ls_kernel(const SolverArgs<R, M> a) {
         for (int t = 0; t < NX; ++t) cn += Math<R>::fabs(c[t]);
 #pragma unroll
         for (int r = 0; r < NX; ++r) {
-          R acc = Psi[r][0] * c[0];
+          W acc = WO::prod(Psi[r][0], c[0]);
 #pragma unroll
-          for (int m = 1; m < NX; ++m) acc += Psi[r][m] * c[m];
+          for (int m = 1; m < NX; ++m) acc += WO::prod(Psi[r][m], c[m]);
           ha[r] += acc;
         }
       }
@@ -761,9 +771,9 @@ __global__ CPMPC_QPLS_BOUNDS void qp_ls_kernel(const SolverArgs<R, M> a) {
     // Psi is now diag(w) Phi_{S-2}...Phi_0: contribution of dx_0 = -c_init
 #pragma unroll
     for (int r = 0; r < NX; ++r) {
-      R acc = Psi[r][0] * ci[0];
+      W acc = WO::prod(Psi[r][0], ci[0]);
 #pragma unroll
-      for (int m = 1; m < NX; ++m) acc += Psi[r][m] * ci[m];
+      for (int m = 1; m < NX; ++m) acc += WO::prod(Psi[r][m], ci[m]);
       hv[r] += ha[r] - acc;
     }
   }
@@ -775,46 +785,53 @@ __global__ CPMPC_QPLS_BOUNDS void qp_ls_kernel(const SolverArgs<R, M> a) {
   // ---- (S + Dg) q = h - rho by LDL^T on the lower triangle, in registers ------------------------
   R q[NX];
   {
-    R Lm[NX][NX], dv[NX];
+    W Lm[NX][NX], dv[NX], idv[NX];
 #pragma unroll
-    for (int i = 0; i < NX; ++i) Sm[i][i] += Dg[i];
+    for (int i = 0; i < NX; ++i) Sm[i][i] += WO::of(Dg[i]);
 #pragma unroll
     for (int j = 0; j < NX; ++j) {
-      R dj = Sm[j][j];
+      W dj = Sm[j][j];
 #pragma unroll
       for (int m = 0; m < j; ++m) dj -= Lm[j][m] * Lm[j][m] * dv[m];
-      if (!(dj > R(0))) pd_ok = false;
+      if (!(dj > W(0))) pd_ok = false;
       dv[j] = dj;
-      const R inv = R(1) / dj;
+      W inv;
+      if constexpr (kWidened) inv = wide_inv<R, W>(dj);
+      else inv = R(1) / dj;
+      idv[j] = inv;
 #pragma unroll
       for (int i = j + 1; i < NX; ++i) {
-        R v = Sm[i][j];
+        W v = Sm[i][j];
 #pragma unroll
         for (int m = 0; m < j; ++m) v -= Lm[i][m] * Lm[j][m] * dv[m];
         Lm[i][j] = v * inv;
       }
     }
-    auto ldl_solve = [&](const R (&b)[NX], R (&x)[NX]) {
-      R y[NX];
+    auto ldl_solve = [&](const W (&b)[NX], W (&x)[NX]) {
+      W y[NX];
 #pragma unroll
       for (int i = 0; i < NX; ++i) {
-        R v = b[i];
+        W v = b[i];
 #pragma unroll
         for (int m = 0; m < i; ++m) v -= Lm[i][m] * y[m];
         y[i] = v;
       }
 #pragma unroll
       for (int i = NX - 1; i >= 0; --i) {
-        R v = y[i] / dv[i];
+        W v;
+        if constexpr (kWidened) v = y[i] * idv[i];
+        else v = y[i] / dv[i];
 #pragma unroll
         for (int m = i + 1; m < NX; ++m) v -= Lm[m][i] * x[m];
         x[i] = v;
       }
     };
-    R rhs[NX];
+    W rhs[NX], qw[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) rhs[i] = hv[i] - rho[i];
-    ldl_solve(rhs, q);
+    ldl_solve(rhs, qw);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) q[i] = (R)qw[i];
     // One step of iterative refinement of q with the residual taken through the factored operator
     // (S = W^T D^-1 W is a normal-equations matrix; see mpc_fused_body.inc).  fp64 only HERE: this kernel is bound by
     // its workspace traffic and the pass re-reads W and T from HBM (+25 % bytes); the fused kernel, where the pass is
