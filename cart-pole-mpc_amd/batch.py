@@ -92,7 +92,11 @@ class BatchOutputs:
 class BatchOptimization:
     """B independent pendulum::Optimization controllers solved in lock-step on one GPU."""
 
-    def __init__(self, params, max_batch, dtype=torch.float32, device=None, opts=None, model="single"):
+    def __init__(self, params, max_batch, dtype=torch.float32, device=None, opts=None, model="single",
+                 allow_long_horizon=False):
+        """allow_long_horizon: accept window_length * control_dt beyond cpmpc_max_parity_horizon() (0.8 s), where the
+        condensed QP is no longer held to 1e-5 of a full-space solve on every problem (include/cpmpc.h,
+        CPMPC_CREATE_ALLOW_LONG_HORIZON); without it such parameters raise CpmpcError(ERR_UNSUPPORTED)."""
         lib = capi.load()
         self.model = capi.MODELS[model]
         self.nx = lib.cpmpc_model_state_dim(self.model)
@@ -107,9 +111,13 @@ class BatchOptimization:
         self.device = int(device)
         self.max_batch = int(max_batch)
         self._h = C.c_void_p()
-        capi.check(lib.cpmpc_create_model(C.byref(params), C.byref(opts) if opts is not None else None,
-                                          _CAPI_DTYPE[dtype], self.max_batch, self.device, self.model,
-                                          C.byref(self._h)))
+        info = capi.CreateInfo(struct_size=C.sizeof(capi.CreateInfo),
+                               flags=capi.CREATE_ALLOW_LONG_HORIZON if allow_long_horizon else 0,
+                               dtype=_CAPI_DTYPE[dtype], model=self.model, device=self.device, reserved=0,
+                               max_batch=self.max_batch, params=C.pointer(params),
+                               opts=C.pointer(opts) if opts is not None else None,
+                               opts_size=C.sizeof(capi.SolverOpts) if opts is not None else 0)
+        capi.check(lib.cpmpc_create_ex(C.byref(info), C.byref(self._h)))
         self.N = int(params.window_length)
         self.S = lib.cpmpc_num_states(self._h)
         self.dim = lib.cpmpc_dim(self._h)

@@ -29,7 +29,7 @@ PIPELINES = {"auto": 0, "split": 1, "fused": 2, 0: 0, 1: 1, 2: 2}
 # every symbol include/cpmpc.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "cpmpc_default_params", "cpmpc_default_solver_opts", "cpmpc_last_error", "cpmpc_device_count",
-    "cpmpc_create", "cpmpc_destroy", "cpmpc_supported_state_spacing", "cpmpc_step_batch",
+    "cpmpc_create", "cpmpc_create_ex", "cpmpc_max_parity_horizon", "cpmpc_destroy", "cpmpc_supported_state_spacing", "cpmpc_step_batch",
     "cpmpc_reset", "cpmpc_set_previous_solution", "cpmpc_get_solution",
     "cpmpc_has_previous_solution", "cpmpc_previous_solution_batch", "cpmpc_dim", "cpmpc_num_states", "cpmpc_dtype",
     "cpmpc_step_batch_host", "cpmpc_step_batch_host_ex", "cpmpc_set_previous_solution_host", "cpmpc_get_solution_host",
@@ -40,7 +40,10 @@ SYMBOLS = [
     "cpmpc_profile_enable", "cpmpc_profile_reset", "cpmpc_profile_read", "cpmpc_kernel_name",
     "cpmpc_sharded_create", "cpmpc_sharded_destroy", "cpmpc_sharded_num_shards", "cpmpc_sharded_device",
     "cpmpc_sharded_handle", "cpmpc_sharded_range", "cpmpc_sharded_reset", "cpmpc_sharded_step_batch_host",
-    "cpmpc_sharded_step_batch",
+    "cpmpc_sharded_step_batch", "cpmpc_sharded_create_ex", "cpmpc_sharded_previous_solution_batch",
+    "cpmpc_sharded_set_previous_solution", "cpmpc_sharded_set_previous_solution_host", "cpmpc_sharded_get_solution",
+    "cpmpc_sharded_get_solution_host", "cpmpc_sharded_step_batch_host_in", "cpmpc_sharded_step_batch_ex",
+    "cpmpc_step_batch_host_in", "cpmpc_set_host_chunk", "cpmpc_host_register", "cpmpc_host_unregister",
 ]
 
 
@@ -123,6 +126,37 @@ class StepHostOutputs(C.Structure):
     ]
 
 
+CREATE_ALLOW_LONG_HORIZON = 1
+
+
+class CreateInfo(C.Structure):
+    """cpmpc_create_info: size-versioned arguments of cpmpc_create_ex."""
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("flags", C.c_uint32),
+        ("dtype", C.c_int32),
+        ("model", C.c_int32),
+        ("device", C.c_int32),
+        ("reserved", C.c_int32),
+        ("max_batch", C.c_int64),
+        ("params", C.POINTER(Params)),
+        ("opts", C.POINTER(SolverOpts)),
+        ("opts_size", C.c_uint64),
+    ]
+
+
+class StepHostInputs(C.Structure):
+    """cpmpc_step_host_inputs: HOST double arrays; exactly one of dyn_shared / dyn."""
+    _fields_ = [
+        ("x0", C.POINTER(C.c_double)),
+        ("dyn_shared", C.POINTER(C.c_double)),
+        ("dyn", C.POINTER(C.c_double)),
+        ("set_point_shared", C.c_double),
+        ("set_point", C.POINTER(C.c_double)),
+        ("terminal_weights", C.POINTER(C.c_double)),
+    ]
+
+
 class CpmpcError(RuntimeError):
     def __init__(self, code, text):
         super().__init__("cpmpc error %d: %s" % (code, text))
@@ -160,6 +194,9 @@ def load():
     L.cpmpc_device_count.restype = i32
     L.cpmpc_create.argtypes = [C.POINTER(Params), C.POINTER(SolverOpts), i32, i64, i32,
                                C.POINTER(vp)]
+    L.cpmpc_create_ex.argtypes = [C.POINTER(CreateInfo), C.POINTER(vp)]
+    L.cpmpc_max_parity_horizon.argtypes = []
+    L.cpmpc_max_parity_horizon.restype = dbl
     L.cpmpc_destroy.argtypes = [vp]
     L.cpmpc_destroy.restype = None
     L.cpmpc_supported_state_spacing.argtypes = [i32]
@@ -209,6 +246,19 @@ def load():
     L.cpmpc_sharded_reset.argtypes = [vp]
     L.cpmpc_sharded_step_batch_host.argtypes = [vp, i64, _dp, _dp, dbl, C.POINTER(StepHostOutputs)]
     L.cpmpc_sharded_step_batch.argtypes = [vp, i64, vp, _dp, dbl, C.POINTER(StepOutputs), vp]
+    L.cpmpc_sharded_create_ex.argtypes = [C.POINTER(CreateInfo), C.POINTER(C.c_int), i32, C.POINTER(vp)]
+    L.cpmpc_sharded_previous_solution_batch.argtypes = [vp]
+    L.cpmpc_sharded_previous_solution_batch.restype = i64
+    L.cpmpc_sharded_set_previous_solution.argtypes = [vp, i64, vp, vp]
+    L.cpmpc_sharded_set_previous_solution_host.argtypes = [vp, i64, _dp]
+    L.cpmpc_sharded_get_solution.argtypes = [vp, i64, vp, vp]
+    L.cpmpc_sharded_get_solution_host.argtypes = [vp, i64, _dp]
+    L.cpmpc_sharded_step_batch_host_in.argtypes = [vp, i64, C.POINTER(StepHostInputs), C.POINTER(StepHostOutputs)]
+    L.cpmpc_sharded_step_batch_ex.argtypes = [vp, i64, C.POINTER(StepInputs), C.POINTER(StepOutputs), vp]
+    L.cpmpc_step_batch_host_in.argtypes = [vp, i64, C.POINTER(StepHostInputs), C.POINTER(StepHostOutputs)]
+    L.cpmpc_set_host_chunk.argtypes = [vp, i64]
+    L.cpmpc_host_register.argtypes = [vp, C.c_uint64]
+    L.cpmpc_host_unregister.argtypes = [vp]
     _lib = L
     return L
 

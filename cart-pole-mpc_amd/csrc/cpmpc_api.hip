@@ -6,7 +6,13 @@
 // translation unit (engine_<dtype>_<model>.hip) and are reached through its `Engine` table (engine.hpp).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <cstdlib>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -151,8 +157,13 @@ static int validate_params(const cpmpc_params* p) {
   return CPMPC_OK;
 }
 
-extern "C" int cpmpc_create_model(const cpmpc_params* params, const cpmpc_solver_opts* opts, int dtype,
-                                  int64_t max_batch, int device, int model, cpmpc_solver** out) {
+// Horizon (window_length * control_dt, seconds) up to which the condensed QP is held to 1e-5 of a full-space KKT solve on
+// every problem (include/cpmpc.h: cpmpc_max_parity_horizon)
+static const double kMaxParityHorizon = 0.8;
+extern "C" double cpmpc_max_parity_horizon(void) { return kMaxParityHorizon; }
+
+static int create_impl(const cpmpc_params* params, const cpmpc_solver_opts* opts, size_t opts_size, int dtype,
+                       int64_t max_batch, int device, int model, uint32_t flags, cpmpc_solver** out) {
   if (!params || !out) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
   *out = nullptr;
   if (dtype != CPMPC_F32 && dtype != CPMPC_F64) return fail(CPMPC_ERR_INVALID_ARG, "dtype must be CPMPC_F32 or CPMPC_F64");
@@ -160,6 +171,18 @@ extern "C" int cpmpc_create_model(const cpmpc_params* params, const cpmpc_solver
   if (max_batch < 1 || max_batch > (1ll << 30)) return fail(CPMPC_ERR_INVALID_ARG, "max_batch must be in [1, 2^30]");
   int rc = validate_params(params);
   if (rc) return rc;
+  if ((flags & ~(uint32_t)CPMPC_CREATE_ALLOW_LONG_HORIZON) != 0) return fail(CPMPC_ERR_INVALID_ARG, "unknown creation flags 0x%x", flags);
+  if (opts != nullptr && (opts_size < sizeof(int32_t) || opts_size > sizeof(cpmpc_solver_opts)))
+    return fail(CPMPC_ERR_INVALID_ARG, "opts_size %zu is not the size of any cpmpc_solver_opts this library knows (at most %zu)",
+                opts_size, sizeof(cpmpc_solver_opts));
+  {
+    const double horizon = (double)params->window_length * params->control_dt;
+    if (horizon > kMaxParityHorizon * (1.0 + 1e-9) && !(flags & CPMPC_CREATE_ALLOW_LONG_HORIZON))
+      return fail(CPMPC_ERR_UNSUPPORTED,
+                  "horizon window_length * control_dt = %.3f s exceeds %.1f s, the longest the condensed QP is held to 1e-5 of a "
+                  "full-space solve on every problem (state elimination through an unstable plant loses ~3 digits per QP at "
+                  "1.6 s); pass CPMPC_CREATE_ALLOW_LONG_HORIZON to cpmpc_create_ex to solve it anyway", horizon, kMaxParityHorizon);
+  }
   rc = check_device(device);
   if (rc) return rc;
   DeviceGuard guard(device);
@@ -167,10 +190,10 @@ extern "C" int cpmpc_create_model(const cpmpc_params* params, const cpmpc_solver
   cpmpc_solver* s = new (std::nothrow) cpmpc_solver();
   if (!s) return fail(CPMPC_ERR_ALLOC, "out of host memory");
   s->params = *params;
-  if (opts)
-    s->opts = *opts;
-  else
-    cpmpc_default_solver_opts(&s->opts);
+  // defaults first, then as many leading bytes as the caller's struct has: a caller compiled against an earlier header
+  // (a shorter struct: fields are only ever appended) keeps this library's defaults for the options it does not know
+  cpmpc_default_solver_opts(&s->opts);
+  if (opts) memcpy(&s->opts, opts, opts_size);
   s->dtype = dtype;
   s->model = model;
   s->device = device;
@@ -240,7 +263,7 @@ extern "C" int cpmpc_create_model(const cpmpc_params* params, const cpmpc_solver
     return fail(CPMPC_ERR_HIP, "hipMemcpy failed: %s", hipGetErrorString(e));
   }
   // index list of the staged fused pipeline (4 bytes per problem + two counters): allocated here, never in a step
-  if (hipMalloc((void**)&s->active, ((size_t)s->cap + 2) * sizeof(int32_t)) != hipSuccess) {
+  if (hipMalloc((void**)&s->active, ((size_t)s->cap + 2 * kHostSlots) * sizeof(int32_t)) != hipSuccess) {
     (void)hipGetLastError();
     s->active = nullptr;  // staging stays off for this handle (same results, single launch)
   }
@@ -248,9 +271,24 @@ extern "C" int cpmpc_create_model(const cpmpc_params* params, const cpmpc_solver
   return CPMPC_OK;
 }
 
+extern "C" int cpmpc_create_model(const cpmpc_params* params, const cpmpc_solver_opts* opts, int dtype,
+                                  int64_t max_batch, int device, int model, cpmpc_solver** out) {
+  return create_impl(params, opts, sizeof(cpmpc_solver_opts), dtype, max_batch, device, model, 0, out);
+}
+
 extern "C" int cpmpc_create(const cpmpc_params* params, const cpmpc_solver_opts* opts, int dtype,
                             int64_t max_batch, int device, cpmpc_solver** out) {
-  return cpmpc_create_model(params, opts, dtype, max_batch, device, CPMPC_MODEL_SINGLE, out);
+  return create_impl(params, opts, sizeof(cpmpc_solver_opts), dtype, max_batch, device, CPMPC_MODEL_SINGLE, 0, out);
+}
+
+extern "C" int cpmpc_create_ex(const cpmpc_create_info* info, cpmpc_solver** out) {
+  if (!info || !out) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
+  *out = nullptr;
+  if (info->struct_size != sizeof(cpmpc_create_info))
+    return fail(CPMPC_ERR_INVALID_ARG, "cpmpc_create_info.struct_size is %u, this library's is %zu (set it to sizeof(cpmpc_create_info))",
+                info->struct_size, sizeof(cpmpc_create_info));
+  const size_t osz = info->opts_size ? (size_t)info->opts_size : sizeof(cpmpc_solver_opts);
+  return create_impl(info->params, info->opts, osz, info->dtype, info->max_batch, info->device, info->model, info->flags, out);
 }
 
 extern "C" void cpmpc_destroy(cpmpc_solver* s) {
@@ -266,9 +304,13 @@ extern "C" void cpmpc_destroy(cpmpc_solver* s) {
   }
   if (s->ws) (void)hipFree(s->ws);
   if (s->sin_table) (void)hipFree(s->sin_table);
-  if (s->stage) (void)hipFree(s->stage);
-  if (s->pin) (void)hipHostFree(s->pin);
-  if (s->hstream) (void)hipStreamDestroy(s->hstream);
+  for (HostSlot& sl : s->slot) {
+    if (sl.stream) (void)hipStreamSynchronize(sl.stream);
+    if (sl.dev) (void)hipFree(sl.dev);
+    if (sl.pin) (void)hipHostFree(sl.pin);
+    if (sl.done) (void)hipEventDestroy(sl.done);
+    if (sl.stream) (void)hipStreamDestroy(sl.stream);
+  }
   if (s->ev_last) (void)hipEventDestroy(s->ev_last);
   if (s->active) (void)hipFree(s->active);
   delete s;
@@ -353,7 +395,9 @@ extern "C" int cpmpc_profile_read(cpmpc_solver* s, int kernel, double* total_ms,
 // Host-pointer entry points run on the handle's own stream.  Once one has been used, every device-pointer call on a
 // caller's stream leaves an event behind so that the next host-pointer call is ordered after it.
 static void track_caller_stream(cpmpc_solver* s, hipStream_t stream) {
-  if (s->ev_last != nullptr && stream != s->hstream) {
+  bool own = false;
+  for (const HostSlot& sl : s->slot) own = own || (sl.stream != nullptr && stream == sl.stream);
+  if (s->ev_last != nullptr && !own) {
     (void)hipEventRecord(s->ev_last, stream);
     s->ev_pending = true;
   }
@@ -396,7 +440,7 @@ extern "C" int cpmpc_step_batch(cpmpc_solver* s, int64_t B, const cpmpc_step_inp
     return fail(CPMPC_ERR_INVALID_ARG, "set_point_shared must be finite");
   DeviceGuard guard(s->device);
   int rc = CPMPC_OK;
-  rc = engine_of(s)->step_batch(s, B, in, out, (hipStream_t)stream);
+  rc = engine_of(s)->step_batch(s, B, in, out, (hipStream_t)stream, 0, 0);
   track_caller_stream(s, (hipStream_t)stream);
   return rc;
 }
@@ -429,53 +473,228 @@ extern "C" int cpmpc_get_solution(cpmpc_solver* s, int64_t B, void* z_out, void*
 }
 
 // ------------------------------------------------------------------------------------------------
-// host-pointer convenience (staging copies around the same GPU path)
+// host-pointer entry points: staging slots, worker threads, the chunk pipeline
 // ------------------------------------------------------------------------------------------------
-int ensure_stage(cpmpc_solver* s, size_t bytes) {
-  if (s->hstream == nullptr) {
-    hipError_t e = hipStreamCreateWithFlags(&s->hstream, hipStreamNonBlocking);
+int ensure_slot(cpmpc_solver* s, int k, size_t bytes) {
+  HostSlot& sl = s->slot[k];
+  if (sl.stream == nullptr) {
+    bool first = true;
+    for (int i = 0; i < kHostSlots; ++i) first = first && s->slot[i].stream == nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking);
     if (e != hipSuccess) return fail(CPMPC_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
-    e = hipEventCreateWithFlags(&s->ev_last, hipEventDisableTiming);
+    e = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming);
+    if (e == hipSuccess && s->ev_last == nullptr) e = hipEventCreateWithFlags(&s->ev_last, hipEventDisableTiming);
     if (e != hipSuccess) return fail(CPMPC_ERR_HIP, "hipEventCreate failed: %s", hipGetErrorString(e));
-    // device-pointer calls made before this first host-pointer call were not tracked by ev_last: order after them once
+    // device-pointer calls made before the first host-pointer call were not tracked by ev_last: order after them once;
+    // a slot stream created later orders itself after whatever the other slots have queued the same way
+    (void)first;
     HIP_TRY(hipDeviceSynchronize());
   }
-  if (s->ev_pending) {  // a device-pointer call on a caller's stream came in between: run after it
-    HIP_TRY(hipStreamWaitEvent(s->hstream, s->ev_last, 0));
+  if (s->ev_pending) {  // a device-pointer call on a caller's stream came in between: every slot stream runs after it
+    for (int i = 0; i < kHostSlots; ++i)
+      if (s->slot[i].stream) HIP_TRY(hipStreamWaitEvent(s->slot[i].stream, s->ev_last, 0));
     s->ev_pending = false;
   }
-  if (s->stage_bytes >= bytes) return CPMPC_OK;
-  if (s->stage) (void)hipFree(s->stage);
-  if (s->pin) (void)hipHostFree(s->pin);
-  s->stage = nullptr;
-  s->pin = nullptr;
-  s->stage_bytes = 0;
+  if (sl.bytes >= bytes) return CPMPC_OK;
+  HIP_TRY(hipStreamSynchronize(sl.stream));
+  if (sl.dev) (void)hipFree(sl.dev);
+  if (sl.pin) (void)hipHostFree(sl.pin);
+  sl.dev = nullptr;
+  sl.pin = nullptr;
+  sl.bytes = 0;
   const size_t want = bytes < 4096 ? 4096 : bytes;
-  hipError_t e = hipMalloc(&s->stage, want);
+  hipError_t e = hipMalloc(&sl.dev, want);
   if (e != hipSuccess) return fail(CPMPC_ERR_ALLOC, "hipMalloc of %zu staging bytes failed: %s", want, hipGetErrorString(e));
-  e = hipHostMalloc(&s->pin, want, hipHostMallocDefault);
+  e = hipHostMalloc(&sl.pin, want, hipHostMallocDefault);
   if (e != hipSuccess) {
-    (void)hipFree(s->stage);
-    s->stage = nullptr;
+    (void)hipFree(sl.dev);
+    sl.dev = nullptr;
     return fail(CPMPC_ERR_ALLOC, "hipHostMalloc of %zu staging bytes failed: %s", want, hipGetErrorString(e));
   }
-  s->stage_bytes = want;
+  sl.bytes = want;
   return CPMPC_OK;
+}
+
+// Worker threads for the CPU side of large host-pointer steps (conversion and scatter of the results: a 262 144-problem
+// fp64 step returns 420 MB, which one thread moves at ~10 GB/s while PCIe delivers 55).  Created on first use, never
+// destroyed (a process-lifetime pool; CPMPC_HOST_THREADS overrides the count, 1 = the calling thread alone).
+namespace {
+struct HostPool {
+  std::mutex m;
+  std::condition_variable cv_work, cv_done;
+  void (*fn)(int64_t, void*) = nullptr;
+  void* ctx = nullptr;
+  int64_t n = 0;
+  std::atomic<int64_t> next{0};
+  uint64_t generation = 0;
+  int running = 0;
+  int workers = 0;
+  std::mutex call;  // one parallel_for at a time
+};
+HostPool* g_pool = nullptr;
+std::once_flag g_pool_once;
+
+void pool_worker(HostPool* p) {
+  uint64_t seen = 0;
+  for (;;) {
+    std::unique_lock<std::mutex> lk(p->m);
+    p->cv_work.wait(lk, [&] { return p->generation != seen; });
+    seen = p->generation;
+    void (*fn)(int64_t, void*) = p->fn;
+    void* ctx = p->ctx;
+    const int64_t n = p->n;
+    lk.unlock();
+    for (int64_t i = p->next.fetch_add(1); i < n; i = p->next.fetch_add(1)) fn(i, ctx);
+    lk.lock();
+    if (--p->running == 0) p->cv_done.notify_all();
+  }
+}
+}  // namespace
+
+void host_parallel_for(int64_t n, void (*fn)(int64_t, void*), void* ctx) {
+  std::call_once(g_pool_once, [] {
+    g_pool = new HostPool();
+    int want = 0;
+    if (const char* e = getenv("CPMPC_HOST_THREADS")) want = atoi(e);
+    if (want <= 0) {
+      const unsigned hw = std::thread::hardware_concurrency();
+      want = hw >= 16 ? 8 : (hw >= 4 ? (int)hw / 2 : 1);
+    }
+    g_pool->workers = want - 1;
+    for (int i = 0; i < g_pool->workers; ++i) std::thread(pool_worker, g_pool).detach();
+  });
+  HostPool* p = g_pool;
+  if (p->workers == 0 || n <= 1) {
+    for (int64_t i = 0; i < n; ++i) fn(i, ctx);
+    return;
+  }
+  std::lock_guard<std::mutex> one(p->call);
+  {
+    std::lock_guard<std::mutex> lk(p->m);
+    p->fn = fn;
+    p->ctx = ctx;
+    p->n = n;
+    p->next.store(0);
+    p->running = p->workers;
+    ++p->generation;
+  }
+  p->cv_work.notify_all();
+  for (int64_t i = p->next.fetch_add(1); i < n; i = p->next.fetch_add(1)) fn(i, ctx);
+  std::unique_lock<std::mutex> lk(p->m);
+  p->cv_done.wait(lk, [&] { return p->running == 0; });
+}
+
+extern "C" int cpmpc_host_register(void* ptr, uint64_t bytes) {
+  if (!ptr || bytes == 0) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
+  const hipError_t e = hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault);
+  if (e != hipSuccess) return fail(CPMPC_ERR_HIP, "hipHostRegister of %llu bytes failed: %s", (unsigned long long)bytes, hipGetErrorString(e));
+  return CPMPC_OK;
+}
+extern "C" int cpmpc_host_unregister(void* ptr) {
+  if (!ptr) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
+  const hipError_t e = hipHostUnregister(ptr);
+  if (e != hipSuccess) return fail(CPMPC_ERR_HIP, "hipHostUnregister failed: %s", hipGetErrorString(e));
+  return CPMPC_OK;
+}
+
+extern "C" int cpmpc_set_host_chunk(cpmpc_solver* s, int64_t problems) {
+  if (!s) return fail(CPMPC_ERR_INVALID_ARG, "null solver");
+  if (problems < 0) return fail(CPMPC_ERR_INVALID_ARG, "chunk size must be >= 0 (0 = never split)");
+  s->host_chunk = problems == 0 ? 0 : (problems + 63) / 64 * 64;
+  return CPMPC_OK;
+}
+
+// One chunk of a host-pointer step: problems [c0, c0 + Bc) of handle h = columns [g0, g0 + Bc) of the caller's arrays
+struct HostWork {
+  cpmpc_solver* h;
+  int64_t c0, Bc, g0;
+};
+
+// the chunks of problems [0, Bh) of handle h (its columns start at g_base in the caller's arrays), appended to `work`
+static void host_chunks_of(cpmpc_solver* h, int64_t Bh, int64_t g_base, std::vector<std::vector<HostWork>>& per_handle) {
+  std::vector<HostWork> w;
+  int64_t n = 1;
+  if (h->host_chunk > 0 && Bh > h->host_chunk + h->host_chunk / 2) n = (Bh + h->host_chunk - 1) / h->host_chunk;
+  const int64_t step = ((Bh + n - 1) / n + 63) / 64 * 64;
+  for (int64_t c0 = 0; c0 < Bh; c0 += step) w.push_back(HostWork{h, c0, (Bh - c0 < step ? Bh - c0 : step), g_base + c0});
+  per_handle.push_back(std::move(w));
+}
+
+// Runs the chunks as a pipeline: a handle's chunks rotate through its kHostSlots staging slots, so that while the CPU
+// scatters one chunk's results the next is copying back and the one after is in the kernels; the chunks of several
+// handles (the shards of cpmpc_sharded_*) are issued round-robin.  Results do not depend on the chunking: a problem's
+// arithmetic does not depend on the lanes it occupies or on its neighbours.  Returns after every chunk has landed.
+static int run_host_pipeline(const std::vector<std::vector<HostWork>>& per_handle, int64_t ld,
+                             const cpmpc_step_host_inputs& in, const cpmpc_step_host_outputs& out) {
+  struct Flight {
+    cpmpc_solver* h;
+    int slot;
+  };
+  std::deque<Flight> inflight;
+  int first_rc = CPMPC_OK;
+  auto end_front = [&]() {
+    const Flight f = inflight.front();
+    inflight.pop_front();
+    DeviceGuard guard(f.h->device);
+    if (first_rc == CPMPC_OK) {
+      const int rc = engine_of(f.h)->host_chunk_end(f.h, f.slot, ld, out);
+      if (rc != CPMPC_OK) first_rc = rc;
+    } else {  // after a failure: drain what was started, deliver nothing more
+      (void)hipStreamSynchronize(f.h->slot[f.slot].stream);
+      f.h->slot[f.slot].busy = false;
+    }
+  };
+  size_t rounds = 0;
+  for (const auto& w : per_handle) rounds = w.size() > rounds ? w.size() : rounds;
+  for (size_t k = 0; k < rounds && first_rc == CPMPC_OK; ++k) {
+    for (const auto& w : per_handle) {
+      if (k >= w.size() || first_rc != CPMPC_OK) continue;
+      const HostWork& c = w[k];
+      const int slot = (int)(k % kHostSlots);
+      while (c.h->slot[slot].busy && !inflight.empty()) end_front();  // oldest first: it is the one most likely done
+      if (first_rc != CPMPC_OK) break;
+      DeviceGuard guard(c.h->device);
+      const int rc = engine_of(c.h)->host_chunk_begin(c.h, slot, c.c0, c.Bc, c.g0, ld, in, out);
+      if (rc != CPMPC_OK) {
+        first_rc = rc;
+        break;
+      }
+      inflight.push_back(Flight{c.h, slot});
+    }
+  }
+  while (!inflight.empty()) end_front();
+  return first_rc;
+}
+
+static int check_host_inputs(const cpmpc_step_host_inputs* in, const cpmpc_step_host_outputs* out) {
+  if (!in || !out) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
+  if (!in->x0) return fail(CPMPC_ERR_INVALID_ARG, "x0 is required");
+  if ((in->dyn_shared == nullptr) == (in->dyn == nullptr))
+    return fail(CPMPC_ERR_INVALID_ARG, "exactly one of dyn_shared / dyn must be given");
+  if (!in->set_point && !std::isfinite(in->set_point_shared))
+    return fail(CPMPC_ERR_INVALID_ARG, "set_point_shared must be finite");
+  return CPMPC_OK;
+}
+
+extern "C" int cpmpc_step_batch_host_in(cpmpc_solver* s, int64_t B, const cpmpc_step_host_inputs* in,
+                                        const cpmpc_step_host_outputs* out) {
+  if (!s) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
+  int rc = check_host_inputs(in, out);
+  if (rc) return rc;
+  if (B < 1) return fail(CPMPC_ERR_INVALID_ARG, "B must be >= 1");
+  if (B > s->cap) return fail(CPMPC_ERR_BATCH, "B exceeds capacity");
+  std::vector<std::vector<HostWork>> work;
+  host_chunks_of(s, B, 0, work);
+  return run_host_pipeline(work, B, *in, *out);
 }
 
 extern "C" int cpmpc_step_batch_host_ex(cpmpc_solver* s, int64_t B, const double* x0_host,
                                         const double* dyn_shared_host, double set_point,
                                         const cpmpc_step_host_outputs* out) {
   if (!s || !x0_host || !dyn_shared_host || !out) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
-  if (B < 1) return fail(CPMPC_ERR_INVALID_ARG, "B must be >= 1");
-  if (B > s->cap) return fail(CPMPC_ERR_BATCH, "B exceeds capacity");
   if (!std::isfinite(set_point)) return fail(CPMPC_ERR_INVALID_ARG, "set_point must be finite");
-  DeviceGuard guard(s->device);
-  int rc = CPMPC_OK;
-  const Engine* e = engine_of(s);
-  rc = e->step_host_begin(s, B, x0_host, B, 0, dyn_shared_host, set_point, out->predicted != nullptr, out->solution != nullptr);
-  if (rc == CPMPC_OK) rc = e->step_host_end(s, B, *out, B, 0);
-  return rc;
+  const cpmpc_step_host_inputs in = {x0_host, dyn_shared_host, nullptr, set_point, nullptr, nullptr};
+  return cpmpc_step_batch_host_in(s, B, &in, out);
 }
 
 extern "C" int cpmpc_step_batch_host(cpmpc_solver* s, int64_t B, const double* x0_host,
@@ -487,51 +706,66 @@ extern "C" int cpmpc_step_batch_host(cpmpc_solver* s, int64_t B, const double* x
   return cpmpc_step_batch_host_ex(s, B, x0_host, dyn_shared_host, set_point, &out);
 }
 
+// packed z [dim][n] in the handle's dtype <-> rows [dim] of the caller's double array [dim][ld] at column g0
+static int set_prev_host_cols(cpmpc_solver* s, int64_t n, const double* z_host, int64_t ld, int64_t g0) {
+  DeviceGuard guard(s->device);
+  const size_t cnt = (size_t)s->dim * (size_t)n;
+  int rc = ensure_slot(s, 0, cnt * s->esize);
+  if (rc) return rc;
+  HostSlot& sl = s->slot[0];
+  for (int r = 0; r < s->dim; ++r) {
+    const double* src = z_host + (size_t)r * (size_t)ld + (size_t)g0;
+    if (s->dtype == CPMPC_F32) {
+      float* h = (float*)sl.pin + (size_t)r * (size_t)n;
+      for (int64_t i = 0; i < n; ++i) h[i] = (float)src[i];
+    } else {
+      memcpy((double*)sl.pin + (size_t)r * (size_t)n, src, (size_t)n * 8);
+    }
+  }
+  HIP_TRY(hipMemcpyAsync(sl.dev, sl.pin, cnt * s->esize, hipMemcpyHostToDevice, sl.stream));
+  rc = cpmpc_set_previous_solution(s, n, sl.dev, sl.stream);
+  const hipError_t e = hipStreamSynchronize(sl.stream);  // also on failure: the copy above still reads the pinned mirror
+  if (rc) return rc;
+  if (e != hipSuccess) return fail(CPMPC_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e));
+  return CPMPC_OK;
+}
+
+static int get_sol_host_cols(cpmpc_solver* s, int64_t n, double* z_host, int64_t ld, int64_t g0) {
+  DeviceGuard guard(s->device);
+  const size_t cnt = (size_t)s->dim * (size_t)n;
+  int rc = ensure_slot(s, 0, cnt * s->esize);
+  if (rc) return rc;
+  HostSlot& sl = s->slot[0];
+  rc = cpmpc_get_solution(s, n, sl.dev, sl.stream);
+  if (rc) return rc;
+  {
+    const hipError_t e = hipMemcpyAsync(sl.pin, sl.dev, cnt * s->esize, hipMemcpyDeviceToHost, sl.stream);
+    const hipError_t e2 = hipStreamSynchronize(sl.stream);  // also on failure: the unpack kernel is in flight
+    if (e != hipSuccess) return fail(CPMPC_ERR_HIP, "hipMemcpyAsync failed: %s", hipGetErrorString(e));
+    if (e2 != hipSuccess) return fail(CPMPC_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e2));
+  }
+  for (int r = 0; r < s->dim; ++r) {
+    double* dst = z_host + (size_t)r * (size_t)ld + (size_t)g0;
+    if (s->dtype == CPMPC_F32) {
+      const float* h = (const float*)sl.pin + (size_t)r * (size_t)n;
+      for (int64_t i = 0; i < n; ++i) dst[i] = (double)h[i];
+    } else {
+      memcpy(dst, (const double*)sl.pin + (size_t)r * (size_t)n, (size_t)n * 8);
+    }
+  }
+  return CPMPC_OK;
+}
+
 extern "C" int cpmpc_set_previous_solution_host(cpmpc_solver* s, int64_t B, const double* z_host) {
   if (!s || !z_host) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
   if (B < 1 || B > s->cap) return fail(CPMPC_ERR_BATCH, "B out of range");
-  DeviceGuard guard(s->device);
-  const size_t n = (size_t)s->dim * (size_t)B;
-  int rc = ensure_stage(s, n * s->esize);
-  if (rc) return rc;
-  if (s->dtype == CPMPC_F32) {
-    float* h = (float*)s->pin;
-    for (size_t i = 0; i < n; ++i) h[i] = (float)z_host[i];
-  } else {
-    memcpy(s->pin, z_host, n * 8);
-  }
-  HIP_TRY(hipMemcpyAsync(s->stage, s->pin, n * s->esize, hipMemcpyHostToDevice, s->hstream));
-  rc = cpmpc_set_previous_solution(s, B, s->stage, s->hstream);
-  if (rc) {
-    (void)hipStreamSynchronize(s->hstream);  // the copy above still reads the pinned mirror
-    return rc;
-  }
-  HIP_TRY(hipStreamSynchronize(s->hstream));
-  return CPMPC_OK;
+  return set_prev_host_cols(s, B, z_host, B, 0);
 }
 
 extern "C" int cpmpc_get_solution_host(cpmpc_solver* s, int64_t B, double* z_host) {
   if (!s || !z_host) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
   if (B < 1 || B > s->cap) return fail(CPMPC_ERR_BATCH, "B out of range");
-  DeviceGuard guard(s->device);
-  const size_t n = (size_t)s->dim * (size_t)B;
-  int rc = ensure_stage(s, n * s->esize);
-  if (rc) return rc;
-  rc = cpmpc_get_solution(s, B, s->stage, s->hstream);
-  if (rc) return rc;
-  {
-    const hipError_t e = hipMemcpyAsync(s->pin, s->stage, n * s->esize, hipMemcpyDeviceToHost, s->hstream);
-    const hipError_t e2 = hipStreamSynchronize(s->hstream);  // also on failure: the unpack kernel is in flight
-    if (e != hipSuccess) return fail(CPMPC_ERR_HIP, "hipMemcpyAsync failed: %s", hipGetErrorString(e));
-    if (e2 != hipSuccess) return fail(CPMPC_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e2));
-  }
-  if (s->dtype == CPMPC_F32) {
-    const float* h = (const float*)s->pin;
-    for (size_t i = 0; i < n; ++i) z_host[i] = (double)h[i];
-  } else {
-    memcpy(z_host, s->pin, n * 8);
-  }
-  return CPMPC_OK;
+  return get_sol_host_cols(s, B, z_host, B, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -541,18 +775,23 @@ struct Shard {
   cpmpc_solver* h = nullptr;
   int device = 0;
   hipStream_t stream = nullptr;   // device-pointer steps of this shard run here
-  hipEvent_t ready = nullptr;     // root stream -> shard stream (inputs are there)
   hipEvent_t done = nullptr;      // shard stream -> root stream (results have landed on the root device)
-  void* buf = nullptr;            // per-shard device staging: [x0 | u | predicted | cost | eq | status | iters]
+  void* buf = nullptr;            // per-shard device staging of the device-pointer step and of the warm-start hand-over
   size_t buf_bytes = 0;
 };
 
 struct cpmpc_sharded {
   std::vector<Shard> shards;
   int dtype = CPMPC_F64;
-  int N = 0, NX = 4;
+  int N = 0, NX = 4, NP = 9, dim = 0;
   size_t esize = 8;
   int64_t cap = 0;
+  hipEvent_t ready = nullptr;  // on the ROOT device: the caller's inputs are there (root stream -> every shard stream)
+  // Warm-start bookkeeping.  The split of a batch depends on its size, so the shards' previous solutions are those of
+  // columns [0, warm_total) split as a batch of dist_B problems is split; a step (or set / get) with another size first
+  // hands the warm start over to the new split (sharded_align).
+  int64_t dist_B = 0;
+  int64_t warm_total = 0;
 };
 
 static void shard_range(int64_t total, int i, int n, int64_t* lo, int64_t* hi) {
@@ -568,17 +807,23 @@ extern "C" void cpmpc_sharded_destroy(cpmpc_sharded* s) {
     if (sh.stream) (void)hipStreamSynchronize(sh.stream);
     if (sh.h) cpmpc_destroy(sh.h);
     if (sh.buf) (void)hipFree(sh.buf);
-    if (sh.ready) (void)hipEventDestroy(sh.ready);
     if (sh.done) (void)hipEventDestroy(sh.done);
     if (sh.stream) (void)hipStreamDestroy(sh.stream);
+  }
+  if (s->ready && !s->shards.empty()) {
+    DeviceGuard guard(s->shards[0].device);
+    (void)hipEventDestroy(s->ready);
   }
   delete s;
 }
 
-extern "C" int cpmpc_sharded_create(const cpmpc_params* params, const cpmpc_solver_opts* opts, int dtype,
-                                    int64_t max_batch, const int* devices, int n_devices, cpmpc_sharded** out) {
-  if (!params || !out) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
+extern "C" int cpmpc_sharded_create_ex(const cpmpc_create_info* info, const int* devices, int n_devices,
+                                       cpmpc_sharded** out) {
+  if (!info || !out) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
   *out = nullptr;
+  if (info->struct_size != sizeof(cpmpc_create_info))
+    return fail(CPMPC_ERR_INVALID_ARG, "cpmpc_create_info.struct_size is %u, this library's is %zu", info->struct_size,
+                sizeof(cpmpc_create_info));
   std::vector<int> devs;
   if (devices == nullptr) {
     int n = 0;
@@ -592,23 +837,25 @@ extern "C" int cpmpc_sharded_create(const cpmpc_params* params, const cpmpc_solv
     devs.assign(devices, devices + n_devices);
   }
   const int n = (int)devs.size();
-  if (max_batch < n) return fail(CPMPC_ERR_INVALID_ARG, "max_batch must be at least the number of shards");
+  if (info->max_batch < n) return fail(CPMPC_ERR_INVALID_ARG, "max_batch must be at least the number of shards");
   cpmpc_sharded* s = new (std::nothrow) cpmpc_sharded();
   if (!s) return fail(CPMPC_ERR_ALLOC, "out of host memory");
-  s->dtype = dtype;
-  s->esize = dtype == CPMPC_F32 ? 4 : 8;
-  s->cap = max_batch;
+  s->dtype = info->dtype;
+  s->esize = info->dtype == CPMPC_F32 ? 4 : 8;
+  s->cap = info->max_batch;
   s->shards.resize(n);
   for (int i = 0; i < n; ++i) {
     Shard& sh = s->shards[i];
     sh.device = devs[i];
     int64_t lo, hi;
-    shard_range(max_batch, i, n, &lo, &hi);
-    int rc = cpmpc_create(params, opts, dtype, hi - lo + 1, sh.device, &sh.h);  // +1: a smaller B may shift a remainder here
+    shard_range(info->max_batch, i, n, &lo, &hi);
+    cpmpc_create_info one = *info;
+    one.device = sh.device;
+    one.max_batch = hi - lo + 1;  // +1: a smaller B may shift a remainder here
+    int rc = cpmpc_create_ex(&one, &sh.h);
     if (rc == CPMPC_OK) {
       DeviceGuard guard(sh.device);
       if (hipStreamCreateWithFlags(&sh.stream, hipStreamNonBlocking) != hipSuccess ||
-          hipEventCreateWithFlags(&sh.ready, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&sh.done, hipEventDisableTiming) != hipSuccess)
         rc = fail(CPMPC_ERR_HIP, "stream / event creation failed on device %d", sh.device);
     }
@@ -619,9 +866,18 @@ extern "C" int cpmpc_sharded_create(const cpmpc_params* params, const cpmpc_solv
   }
   s->N = s->shards[0].h->N;
   s->NX = s->shards[0].h->NX;
+  s->NP = s->shards[0].h->NP;
+  s->dim = s->shards[0].h->dim;
+  const int root = s->shards[0].device;
+  {  // an event may only be recorded on a stream of the device it was created on: `ready` belongs to the ROOT device
+    DeviceGuard guard(root);
+    if (hipEventCreateWithFlags(&s->ready, hipEventDisableTiming) != hipSuccess) {
+      cpmpc_sharded_destroy(s);
+      return fail(CPMPC_ERR_HIP, "event creation failed on device %d", root);
+    }
+  }
   // peer access between the root device and every other shard's device (both directions); a pair that cannot be
   // mapped still works, the copies then go through host memory
-  const int root = s->shards[0].device;
   for (int i = 1; i < n; ++i) {
     const int d = s->shards[i].device;
     if (d == root) continue;
@@ -640,6 +896,20 @@ extern "C" int cpmpc_sharded_create(const cpmpc_params* params, const cpmpc_solv
   return CPMPC_OK;
 }
 
+extern "C" int cpmpc_sharded_create(const cpmpc_params* params, const cpmpc_solver_opts* opts, int dtype,
+                                    int64_t max_batch, const int* devices, int n_devices, cpmpc_sharded** out) {
+  if (!params || !out) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
+  cpmpc_create_info info;
+  memset(&info, 0, sizeof info);
+  info.struct_size = sizeof info;
+  info.dtype = dtype;
+  info.model = CPMPC_MODEL_SINGLE;
+  info.max_batch = max_batch;
+  info.params = params;
+  info.opts = opts;
+  return cpmpc_sharded_create_ex(&info, devices, n_devices, out);
+}
+
 extern "C" int cpmpc_sharded_num_shards(const cpmpc_sharded* s) { return s ? (int)s->shards.size() : -1; }
 extern "C" int cpmpc_sharded_device(const cpmpc_sharded* s, int shard) {
   return (s && shard >= 0 && shard < (int)s->shards.size()) ? s->shards[shard].device : -1;
@@ -656,51 +926,16 @@ extern "C" int cpmpc_sharded_range(const cpmpc_sharded* s, int shard, int64_t B,
 extern "C" int cpmpc_sharded_reset(cpmpc_sharded* s) {
   if (!s) return fail(CPMPC_ERR_INVALID_ARG, "null solver");
   for (auto& sh : s->shards) cpmpc_reset(sh.h);
+  s->dist_B = 0;
+  s->warm_total = 0;
   return CPMPC_OK;
 }
+extern "C" int64_t cpmpc_sharded_previous_solution_batch(const cpmpc_sharded* s) { return s ? s->warm_total : 0; }
 
 static int sharded_check(const cpmpc_sharded* s, int64_t B) {
   if (B < 1) return fail(CPMPC_ERR_INVALID_ARG, "B must be >= 1");
   if (B > s->cap) return fail(CPMPC_ERR_BATCH, "B=%lld exceeds the capacity %lld given to cpmpc_sharded_create", (long long)B, (long long)s->cap);
   return CPMPC_OK;
-}
-
-extern "C" int cpmpc_sharded_step_batch_host(cpmpc_sharded* s, int64_t B, const double* x0_host,
-                                             const double* dyn_shared_host, double set_point,
-                                             const cpmpc_step_host_outputs* out) {
-  if (!s || !x0_host || !dyn_shared_host || !out) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
-  if (!std::isfinite(set_point)) return fail(CPMPC_ERR_INVALID_ARG, "set_point must be finite");
-  int rc = sharded_check(s, B);
-  if (rc) return rc;
-  const int n = (int)s->shards.size();
-  // every shard's upload, kernels and download are queued on its own stream before anybody is waited for
-  int begun = 0;
-  for (int i = 0; i < n && rc == CPMPC_OK; ++i) {
-    int64_t lo, hi;
-    shard_range(B, i, n, &lo, &hi);
-    if (hi == lo) continue;
-    Shard& sh = s->shards[i];
-    DeviceGuard guard(sh.device);
-    rc = engine_of(sh.h)->step_host_begin(sh.h, hi - lo, x0_host, B, lo, dyn_shared_host, set_point,
-                                          out->predicted != nullptr, out->solution != nullptr);
-    if (rc == CPMPC_OK) begun = i + 1;
-  }
-  int first_rc = rc;
-  for (int i = 0; i < begun; ++i) {   // also after a failure: drain what was started
-    int64_t lo, hi;
-    shard_range(B, i, n, &lo, &hi);
-    if (hi == lo) continue;
-    Shard& sh = s->shards[i];
-    DeviceGuard guard(sh.device);
-    int rc_i = CPMPC_OK;
-    if (first_rc == CPMPC_OK) {
-      rc_i = engine_of(sh.h)->step_host_end(sh.h, hi - lo, *out, B, lo);
-      if (rc_i != CPMPC_OK) first_rc = rc_i;
-    } else {
-      (void)hipStreamSynchronize(sh.h->hstream);
-    }
-  }
-  return first_rc;
 }
 
 static int ensure_shard_buf(Shard& sh, size_t bytes) {
@@ -714,47 +949,178 @@ static int ensure_shard_buf(Shard& sh, size_t bytes) {
   return CPMPC_OK;
 }
 
-extern "C" int cpmpc_sharded_step_batch(cpmpc_sharded* s, int64_t B, const void* x0, const double* dyn_shared_host,
-                                        double set_point, const cpmpc_step_outputs* out, void* stream) {
-  if (!s || !x0 || !dyn_shared_host || !out) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
+// How many of shard i's problems, split as a batch of `dist` problems is split, lie in columns [0, warm)
+static int64_t warm_in_shard(int64_t dist, int i, int n, int64_t warm, int64_t* lo_out) {
+  int64_t lo, hi;
+  shard_range(dist, i, n, &lo, &hi);
+  if (lo_out) *lo_out = lo;
+  const int64_t w = warm - lo;
+  return w < 0 ? 0 : (w > hi - lo ? hi - lo : w);
+}
+
+// The shards hold the previous solutions of columns [0, warm_total) split as a batch of dist_B problems is split.  A call
+// with another batch size B would pair every shard's warm start with other columns: hand the warm start over to B's
+// split first -- gather z of the warm columns on the root device, reset, scatter by the new ranges.  Columns beyond B
+// are dropped (a single handle would keep them; a sharded one has nowhere to put them).  Rare and synchronous.
+static int sharded_align(cpmpc_sharded* s, int64_t B) {
+  if (s->warm_total == 0 || s->dist_B == B) {
+    if (s->warm_total == 0) s->dist_B = B;
+    return CPMPC_OK;
+  }
+  const int n = (int)s->shards.size();
+  const int64_t W = s->warm_total;
+  const size_t es = s->esize, dim = (size_t)s->dim;
+  const int root = s->shards[0].device;
+  void* tmp = nullptr;
+  {
+    DeviceGuard guard(root);
+    HIP_TRY(hipMalloc(&tmp, dim * (size_t)W * es));
+  }
+  int rc = CPMPC_OK;
+  auto body = [&]() -> int {
+    for (int i = 0; i < n; ++i) {  // gather [dim][n_i] of every shard into columns [lo_i, lo_i + n_i) of tmp [dim][W]
+      int64_t lo;
+      const int64_t ni = warm_in_shard(s->dist_B, i, n, W, &lo);
+      if (ni == 0) continue;
+      Shard& sh = s->shards[i];
+      DeviceGuard guard(sh.device);
+      int r = ensure_shard_buf(sh, dim * (size_t)ni * es);
+      if (r) return r;
+      r = cpmpc_get_solution(sh.h, ni, sh.buf, sh.stream);
+      if (r) return r;
+      HIP_TRY(hipMemcpy2DAsync((char*)tmp + (size_t)lo * es, (size_t)W * es, sh.buf, (size_t)ni * es, (size_t)ni * es, dim,
+                               hipMemcpyDefault, sh.stream));
+      HIP_TRY(hipStreamSynchronize(sh.stream));
+    }
+    for (auto& sh : s->shards) cpmpc_reset(sh.h);
+    const int64_t keep = W < B ? W : B;
+    for (int i = 0; i < n; ++i) {
+      int64_t lo;
+      const int64_t ni = warm_in_shard(B, i, n, keep, &lo);
+      if (ni == 0) continue;
+      Shard& sh = s->shards[i];
+      DeviceGuard guard(sh.device);
+      int r = ensure_shard_buf(sh, dim * (size_t)ni * es);
+      if (r) return r;
+      HIP_TRY(hipMemcpy2DAsync(sh.buf, (size_t)ni * es, (const char*)tmp + (size_t)lo * es, (size_t)W * es, (size_t)ni * es, dim,
+                               hipMemcpyDefault, sh.stream));
+      r = cpmpc_set_previous_solution(sh.h, ni, sh.buf, sh.stream);
+      if (r) return r;
+      HIP_TRY(hipStreamSynchronize(sh.stream));
+    }
+    s->dist_B = B;
+    s->warm_total = keep;
+    return CPMPC_OK;
+  };
+  rc = body();
+  {
+    DeviceGuard guard(root);
+    for (auto& sh : s->shards) (void)hipStreamSynchronize(sh.stream);
+    (void)hipFree(tmp);
+  }
+  if (rc != CPMPC_OK) {  // half-moved warm starts are worse than none
+    for (auto& sh : s->shards) cpmpc_reset(sh.h);
+    s->dist_B = B;
+    s->warm_total = 0;
+  }
+  return rc;
+}
+
+extern "C" int cpmpc_sharded_step_batch_host_in(cpmpc_sharded* s, int64_t B, const cpmpc_step_host_inputs* in,
+                                                const cpmpc_step_host_outputs* out) {
+  if (!s) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
+  int rc = check_host_inputs(in, out);
+  if (rc) return rc;
+  rc = sharded_check(s, B);
+  if (rc) return rc;
+  rc = sharded_align(s, B);
+  if (rc) return rc;
+  const int n = (int)s->shards.size();
+  // every shard's chunks -- upload, kernels, download on its own streams -- are in flight together
+  std::vector<std::vector<HostWork>> work;
+  for (int i = 0; i < n; ++i) {
+    int64_t lo, hi;
+    shard_range(B, i, n, &lo, &hi);
+    if (hi > lo) host_chunks_of(s->shards[i].h, hi - lo, lo, work);
+  }
+  rc = run_host_pipeline(work, B, *in, *out);
+  if (rc == CPMPC_OK) s->warm_total = B;
+  else cpmpc_sharded_reset(s);  // some shards stepped, others did not: no consistent warm start is left
+  return rc;
+}
+
+extern "C" int cpmpc_sharded_step_batch_host(cpmpc_sharded* s, int64_t B, const double* x0_host,
+                                             const double* dyn_shared_host, double set_point,
+                                             const cpmpc_step_host_outputs* out) {
+  if (!s || !x0_host || !dyn_shared_host || !out) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
   if (!std::isfinite(set_point)) return fail(CPMPC_ERR_INVALID_ARG, "set_point must be finite");
-  if (out->guess || out->solution || out->ls_evals)
-    return fail(CPMPC_ERR_UNSUPPORTED, "guess / solution / ls_evals are not gathered by the sharded step");
+  const cpmpc_step_host_inputs in = {x0_host, dyn_shared_host, nullptr, set_point, nullptr, nullptr};
+  return cpmpc_sharded_step_batch_host_in(s, B, &in, out);
+}
+
+extern "C" int cpmpc_sharded_step_batch_ex(cpmpc_sharded* s, int64_t B, const cpmpc_step_inputs* in,
+                                           const cpmpc_step_outputs* out, void* stream) {
+  if (!s || !in || !out) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
+  if (!in->x0) return fail(CPMPC_ERR_INVALID_ARG, "x0 is required");
+  if ((in->dyn_shared_host == nullptr) == (in->dyn == nullptr))
+    return fail(CPMPC_ERR_INVALID_ARG, "exactly one of dyn_shared_host / dyn must be given");
+  if (!in->set_point && !std::isfinite(in->set_point_shared))
+    return fail(CPMPC_ERR_INVALID_ARG, "set_point_shared must be finite");
   int rc = sharded_check(s, B);
+  if (rc) return rc;
+  rc = sharded_align(s, B);
   if (rc) return rc;
   const int n = (int)s->shards.size();
   const size_t es = s->esize;
   const hipStream_t root_stream = (hipStream_t)stream;
   const int root = s->shards[0].device;
-  const size_t NX = (size_t)s->NX, N = (size_t)s->N;
-  // the caller's inputs are ready where its stream is now
+  const size_t NX = (size_t)s->NX, N = (size_t)s->N, NP = (size_t)s->NP, dim = (size_t)s->dim;
+  // the caller's inputs are ready where its stream is now: ONE event of the root device, every shard stream waits on it
   {
     DeviceGuard guard(root);
-    for (int i = 0; i < n; ++i) HIP_TRY(hipEventRecord(s->shards[i].ready, root_stream));
+    HIP_TRY(hipEventRecord(s->ready, root_stream));
   }
-  for (int i = 0; i < n; ++i) {
+  int started = 0;
+  auto one_shard = [&](int i) -> int {
     int64_t lo, hi;
     shard_range(B, i, n, &lo, &hi);
-    if (hi == lo) continue;
+    if (hi == lo) return CPMPC_OK;
     const size_t Bs = (size_t)(hi - lo);
     Shard& sh = s->shards[i];
     DeviceGuard guard(sh.device);
-    // per-shard staging on the shard's own device, 256-byte aligned pieces
-    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    const size_t o_x0 = 0, o_u = al(NX * Bs * es), o_pred = o_u + al(N * Bs * es), o_cost = o_pred + al(N * NX * Bs * es),
-                 o_eq = o_cost + al(Bs * es), o_st = o_eq + al(Bs * es), o_it = o_st + al(Bs * 4), o_end = o_it + al(Bs * 4);
-    rc = ensure_shard_buf(sh, o_end);
-    if (rc) return rc;
+    // per-shard staging on the shard's own device, 256-byte aligned pieces (absent arrays take no room)
+    size_t off = 0;
+    auto piece = [&](bool present, size_t bytes) {
+      const size_t o = off;
+      if (present) off += (bytes + 255) & ~(size_t)255;
+      return o;
+    };
+    const size_t o_x0 = piece(true, NX * Bs * es), o_dyn = piece(in->dyn != nullptr, NP * Bs * es),
+                 o_sp = piece(in->set_point != nullptr, Bs * es), o_tw = piece(in->terminal_weights != nullptr, NX * Bs * es),
+                 o_u = piece(out->u != nullptr, N * Bs * es), o_pred = piece(out->predicted != nullptr, N * NX * Bs * es),
+                 o_cost = piece(out->final_cost != nullptr, Bs * es), o_eq = piece(out->final_eq_l1 != nullptr, Bs * es),
+                 o_st = piece(out->status != nullptr, Bs * 4), o_it = piece(out->iterations != nullptr, Bs * 4),
+                 o_ls = piece(out->ls_evals != nullptr, Bs * 4), o_guess = piece(out->guess != nullptr, dim * Bs * es),
+                 o_sol = piece(out->solution != nullptr, dim * Bs * es);
+    int r = ensure_shard_buf(sh, off ? off : 256);
+    if (r) return r;
     char* b = (char*)sh.buf;
-    HIP_TRY(hipStreamWaitEvent(sh.stream, sh.ready, 0));
-    // scatter: my columns of x0 [NX][B] (root device) -> [NX][Bs] here
-    HIP_TRY(hipMemcpy2DAsync(b + o_x0, Bs * es, (const char*)x0 + (size_t)lo * es, (size_t)B * es, Bs * es, NX,
-                             hipMemcpyDefault, sh.stream));
-    cpmpc_step_inputs in;
-    memset(&in, 0, sizeof in);
-    in.x0 = b + o_x0;
-    in.dyn_shared_host = dyn_shared_host;
-    in.set_point_shared = set_point;
+    HIP_TRY(hipStreamWaitEvent(sh.stream, s->ready, 0));
+    started = i + 1;  // from here on work of this call is (or may be) in flight on sh.stream
+    // scatter: my columns of an [rows][B] array on the root device -> [rows][Bs] here
+    auto scatter = [&](const void* src, size_t o, size_t rows) -> hipError_t {
+      return hipMemcpy2DAsync(b + o, Bs * es, (const char*)src + (size_t)lo * es, (size_t)B * es, Bs * es, rows,
+                              hipMemcpyDefault, sh.stream);
+    };
+    HIP_TRY(scatter(in->x0, o_x0, NX));
+    if (in->dyn) HIP_TRY(scatter(in->dyn, o_dyn, NP));
+    if (in->set_point) HIP_TRY(scatter(in->set_point, o_sp, 1));
+    if (in->terminal_weights) HIP_TRY(scatter(in->terminal_weights, o_tw, NX));
+    cpmpc_step_inputs si = *in;
+    si.x0 = b + o_x0;
+    si.dyn = in->dyn ? b + o_dyn : nullptr;
+    si.set_point = in->set_point ? b + o_sp : nullptr;
+    si.terminal_weights = in->terminal_weights ? b + o_tw : nullptr;
     cpmpc_step_outputs o;
     memset(&o, 0, sizeof o);
     o.u = out->u ? b + o_u : nullptr;
@@ -763,8 +1129,11 @@ extern "C" int cpmpc_sharded_step_batch(cpmpc_sharded* s, int64_t B, const void*
     o.final_eq_l1 = out->final_eq_l1 ? b + o_eq : nullptr;
     o.status = out->status ? (int32_t*)(b + o_st) : nullptr;
     o.iterations = out->iterations ? (int32_t*)(b + o_it) : nullptr;
-    rc = cpmpc_step_batch(sh.h, (int64_t)Bs, &in, &o, sh.stream);
-    if (rc) return rc;
+    o.ls_evals = out->ls_evals ? (int32_t*)(b + o_ls) : nullptr;
+    o.guess = out->guess ? b + o_guess : nullptr;
+    o.solution = out->solution ? b + o_sol : nullptr;
+    r = cpmpc_step_batch(sh.h, (int64_t)Bs, &si, &o, sh.stream);
+    if (r) return r;
     // gather: rows of Bs scalars here -> rows of B scalars on the root device, at column lo
     auto gather = [&](void* dst, const void* src, size_t rows, size_t e) -> hipError_t {
       if (!dst) return hipSuccess;
@@ -777,7 +1146,21 @@ extern "C" int cpmpc_sharded_step_batch(cpmpc_sharded* s, int64_t B, const void*
     HIP_TRY(gather(out->final_eq_l1, b + o_eq, 1, es));
     HIP_TRY(gather(out->status, b + o_st, 1, 4));
     HIP_TRY(gather(out->iterations, b + o_it, 1, 4));
+    HIP_TRY(gather(out->ls_evals, b + o_ls, 1, 4));
+    HIP_TRY(gather(out->guess, b + o_guess, dim, es));
+    HIP_TRY(gather(out->solution, b + o_sol, dim, es));
     HIP_TRY(hipEventRecord(sh.done, sh.stream));
+    return CPMPC_OK;
+  };
+  for (int i = 0; i < n && rc == CPMPC_OK; ++i) rc = one_shard(i);
+  if (rc != CPMPC_OK) {
+    // copies of the shards already started are still writing the caller's arrays: wait for them before reporting
+    for (int i = 0; i < started; ++i) {
+      DeviceGuard guard(s->shards[i].device);
+      (void)hipStreamSynchronize(s->shards[i].stream);
+    }
+    cpmpc_sharded_reset(s);  // some shards stepped, others did not
+    return rc;
   }
   {
     DeviceGuard guard(root);
@@ -786,6 +1169,165 @@ extern "C" int cpmpc_sharded_step_batch(cpmpc_sharded* s, int64_t B, const void*
       shard_range(B, i, n, &lo, &hi);
       if (hi > lo) HIP_TRY(hipStreamWaitEvent(root_stream, s->shards[i].done, 0));
     }
+  }
+  s->warm_total = B;
+  return CPMPC_OK;
+}
+
+extern "C" int cpmpc_sharded_step_batch(cpmpc_sharded* s, int64_t B, const void* x0, const double* dyn_shared_host,
+                                        double set_point, const cpmpc_step_outputs* out, void* stream) {
+  if (!s || !x0 || !dyn_shared_host || !out) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
+  cpmpc_step_inputs in;
+  memset(&in, 0, sizeof in);
+  in.x0 = x0;
+  in.dyn_shared_host = dyn_shared_host;
+  in.set_point_shared = set_point;
+  return cpmpc_sharded_step_batch_ex(s, B, &in, out, stream);
+}
+
+// Optimization::SetPreviousSolution over all shards (optimization.hpp:86-89): z is [dim][B] on the root device, in the
+// handle's dtype.  Replaces whatever warm start the shards held.
+extern "C" int cpmpc_sharded_set_previous_solution(cpmpc_sharded* s, int64_t B, const void* z, void* stream) {
+  if (!s || !z) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
+  int rc = sharded_check(s, B);
+  if (rc) return rc;
+  cpmpc_sharded_reset(s);
+  const int n = (int)s->shards.size();
+  const size_t es = s->esize, dim = (size_t)s->dim;
+  const int root = s->shards[0].device;
+  {
+    DeviceGuard guard(root);
+    HIP_TRY(hipEventRecord(s->ready, (hipStream_t)stream));
+  }
+  int started = 0;
+  for (int i = 0; i < n && rc == CPMPC_OK; ++i) {
+    int64_t lo, hi;
+    shard_range(B, i, n, &lo, &hi);
+    if (hi == lo) continue;
+    const size_t Bs = (size_t)(hi - lo);
+    Shard& sh = s->shards[i];
+    DeviceGuard guard(sh.device);
+    rc = ensure_shard_buf(sh, dim * Bs * es);
+    if (rc) break;
+    hipError_t e = hipStreamWaitEvent(sh.stream, s->ready, 0);
+    started = i + 1;
+    if (e == hipSuccess)
+      e = hipMemcpy2DAsync(sh.buf, Bs * es, (const char*)z + (size_t)lo * es, (size_t)B * es, Bs * es, dim, hipMemcpyDefault, sh.stream);
+    if (e != hipSuccess) {
+      rc = fail(CPMPC_ERR_HIP, "scatter of the previous solution failed: %s", hipGetErrorString(e));
+      break;
+    }
+    rc = cpmpc_set_previous_solution(sh.h, (int64_t)Bs, sh.buf, sh.stream);
+    if (rc == CPMPC_OK && hipEventRecord(sh.done, sh.stream) != hipSuccess) rc = fail(CPMPC_ERR_HIP, "hipEventRecord failed");
+  }
+  if (rc != CPMPC_OK) {
+    for (int i = 0; i < started; ++i) {
+      DeviceGuard guard(s->shards[i].device);
+      (void)hipStreamSynchronize(s->shards[i].stream);
+    }
+    cpmpc_sharded_reset(s);
+    return rc;
+  }
+  {  // the caller may reuse z once its stream passes this point
+    DeviceGuard guard(root);
+    for (int i = 0; i < n; ++i) {
+      int64_t lo, hi;
+      shard_range(B, i, n, &lo, &hi);
+      if (hi > lo) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, s->shards[i].done, 0));
+    }
+  }
+  s->dist_B = B;
+  s->warm_total = B;
+  return CPMPC_OK;
+}
+
+// The warm start of columns [0, B), B <= cpmpc_sharded_previous_solution_batch(): z_out is [dim][B] on the root device.
+extern "C" int cpmpc_sharded_get_solution(cpmpc_sharded* s, int64_t B, void* z_out, void* stream) {
+  if (!s || !z_out) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
+  int rc = sharded_check(s, B);
+  if (rc) return rc;
+  if (B > s->warm_total)
+    return fail(CPMPC_ERR_BATCH, "only %lld problems hold a previous solution, %lld asked for", (long long)s->warm_total, (long long)B);
+  const int n = (int)s->shards.size();
+  const size_t es = s->esize, dim = (size_t)s->dim;
+  const int root = s->shards[0].device;
+  {
+    DeviceGuard guard(root);
+    HIP_TRY(hipEventRecord(s->ready, (hipStream_t)stream));  // z_out is free for writing from here on
+  }
+  int started = 0;
+  std::vector<int> used;
+  for (int i = 0; i < n && rc == CPMPC_OK; ++i) {
+    int64_t lo;
+    const int64_t ni = warm_in_shard(s->dist_B, i, n, B, &lo);  // the shards' columns follow dist_B's split
+    if (ni == 0) continue;
+    Shard& sh = s->shards[i];
+    DeviceGuard guard(sh.device);
+    rc = ensure_shard_buf(sh, dim * (size_t)ni * es);
+    if (rc) break;
+    hipError_t e = hipStreamWaitEvent(sh.stream, s->ready, 0);
+    started = i + 1;
+    if (e != hipSuccess) {
+      rc = fail(CPMPC_ERR_HIP, "hipStreamWaitEvent failed: %s", hipGetErrorString(e));
+      break;
+    }
+    rc = cpmpc_get_solution(sh.h, ni, sh.buf, sh.stream);
+    if (rc) break;
+    e = hipMemcpy2DAsync((char*)z_out + (size_t)lo * es, (size_t)B * es, sh.buf, (size_t)ni * es, (size_t)ni * es, dim,
+                         hipMemcpyDefault, sh.stream);
+    if (e == hipSuccess) e = hipEventRecord(sh.done, sh.stream);
+    if (e != hipSuccess) {
+      rc = fail(CPMPC_ERR_HIP, "gather of the solution failed: %s", hipGetErrorString(e));
+      break;
+    }
+    used.push_back(i);
+  }
+  if (rc != CPMPC_OK) {
+    for (int i = 0; i < started; ++i) {
+      DeviceGuard guard(s->shards[i].device);
+      (void)hipStreamSynchronize(s->shards[i].stream);
+    }
+    return rc;
+  }
+  DeviceGuard guard(root);
+  for (int i : used) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, s->shards[i].done, 0));
+  return CPMPC_OK;
+}
+
+extern "C" int cpmpc_sharded_set_previous_solution_host(cpmpc_sharded* s, int64_t B, const double* z_host) {
+  if (!s || !z_host) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
+  int rc = sharded_check(s, B);
+  if (rc) return rc;
+  cpmpc_sharded_reset(s);
+  const int n = (int)s->shards.size();
+  for (int i = 0; i < n; ++i) {
+    int64_t lo, hi;
+    shard_range(B, i, n, &lo, &hi);
+    if (hi == lo) continue;
+    rc = set_prev_host_cols(s->shards[i].h, hi - lo, z_host, B, lo);
+    if (rc) {
+      cpmpc_sharded_reset(s);
+      return rc;
+    }
+  }
+  s->dist_B = B;
+  s->warm_total = B;
+  return CPMPC_OK;
+}
+
+extern "C" int cpmpc_sharded_get_solution_host(cpmpc_sharded* s, int64_t B, double* z_host) {
+  if (!s || !z_host) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
+  int rc = sharded_check(s, B);
+  if (rc) return rc;
+  if (B > s->warm_total)
+    return fail(CPMPC_ERR_BATCH, "only %lld problems hold a previous solution, %lld asked for", (long long)s->warm_total, (long long)B);
+  const int n = (int)s->shards.size();
+  for (int i = 0; i < n; ++i) {
+    int64_t lo;
+    const int64_t ni = warm_in_shard(s->dist_B, i, n, B, &lo);
+    if (ni == 0) continue;
+    rc = get_sol_host_cols(s->shards[i].h, ni, z_host, B, lo);
+    if (rc) return rc;
   }
   return CPMPC_OK;
 }

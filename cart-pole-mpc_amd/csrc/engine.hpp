@@ -32,6 +32,24 @@ struct ProfSpan {
   hipEvent_t start, stop;
 };
 
+// Staging of the host-pointer entry points: a device buffer, its pinned host mirror, a stream and an event.  A handle
+// owns kHostSlots of them so that a large host-pointer step runs as a pipeline of chunks: while the CPU scatters chunk k's
+// results into the caller's arrays, chunk k+1 is copying back and chunk k+2 is in the kernels.
+constexpr int kHostSlots = 3;
+struct HostSlot {
+  void* dev = nullptr;
+  void* pin = nullptr;
+  size_t bytes = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t done = nullptr;  // the copy back of the chunk in flight has landed in `pin`
+  // the chunk in flight (host_chunk_begin -> host_chunk_end)
+  bool busy = false;
+  int64_t c0 = 0, Bc = 0, g0 = 0;   // first problem in the handle's workspace, problems, first column in the caller's arrays
+  bool want_pred = false, want_sol = false;
+  bool direct = false;              // real-typed outputs were copied straight into the caller's (pinned) arrays
+  bool per_dyn = false, per_sp = false, per_tw = false;  // which per-problem inputs the chunk carried (staging layout)
+};
+
 struct cpmpc_solver {
   cpmpc_params params;
   cpmpc_solver_opts opts;
@@ -48,14 +66,10 @@ struct cpmpc_solver {
   int32_t* ist;
   void* sin_table = nullptr;
   int64_t prev_B = 0;  // problems [0, prev_B) hold a previous solution; Reset() -> 0
-  // staging for the *_host entry points (lazily allocated, grown on demand, owned by the handle): a device buffer,
-  // its pinned host mirror and a stream, so that a host-pointer call is one async copy in, the kernels, one async
-  // copy out and a single synchronisation
-  void* stage = nullptr;
-  void* pin = nullptr;
-  size_t stage_bytes = 0;
-  hipStream_t hstream = nullptr;
-  hipEvent_t ev_last = nullptr;  // end of the last device-pointer call on a caller's stream; hstream waits on it
+  // staging for the *_host entry points (lazily allocated, grown on demand, owned by the handle)
+  HostSlot slot[kHostSlots];
+  int64_t host_chunk = 32768;    // problems per chunk of a pipelined host-pointer step (cpmpc_set_host_chunk)
+  hipEvent_t ev_last = nullptr;  // end of the last device-pointer call on a caller's stream; the slot streams wait on it
   bool ev_pending = false;
   // profiling
   int profiling = 0;
@@ -74,7 +88,9 @@ struct cpmpc_solver {
 // owned by the API unit
 CPMPC_HIDDEN void span_begin(cpmpc_solver* s, int kernel, hipStream_t stream, ProfSpan* cur);
 CPMPC_HIDDEN void span_end(cpmpc_solver* s, hipStream_t stream, ProfSpan* cur);
-CPMPC_HIDDEN int ensure_stage(cpmpc_solver* s, size_t bytes);
+CPMPC_HIDDEN int ensure_slot(cpmpc_solver* s, int slot, size_t bytes);
+// run fn(i) for i in [0, n) on the library's worker threads (the calling thread takes part); returns when all are done
+CPMPC_HIDDEN void host_parallel_for(int64_t n, void (*fn)(int64_t i, void* ctx), void* ctx);
 
 // fused pipeline: compiled specialisations for these (L = S-1, SP) pairs ...
 static inline bool fused_static(int L, int SP) {  // the default horizon's spacings (N = 40) and N = 20
@@ -106,12 +122,15 @@ static inline bool use_fused(const cpmpc_solver* s) {
 // Entry points of one (dtype, model) pair; every function launches the kernels of its own translation unit.
 struct Engine {
   // Optimization::Step for B problems on `stream` (optimization.cc:39-97)
+  // (col0: first problem of the handle's workspace the call works on; slot: which pair of compaction counters)
   int (*step_batch)(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* in, const cpmpc_step_outputs* out,
-                    hipStream_t stream);
-  // a host-pointer step in two halves (upload + kernels + download queued; wait + scatter)
-  int (*step_host_begin)(cpmpc_solver* s, int64_t B, const double* x0_host, int64_t ld, int64_t col0,
-                         const double* dyn_shared_host, double set_point, bool want_pred, bool want_sol);
-  int (*step_host_end)(cpmpc_solver* s, int64_t B, const cpmpc_step_host_outputs& ho, int64_t ld, int64_t col0);
+                    hipStream_t stream, int64_t col0, int slot);
+  // one chunk of a host-pointer step in two halves: `begin` converts and uploads problems [c0, c0 + Bc) of the handle
+  // (columns [g0, g0 + Bc) of the caller's [field][ld] arrays), queues the kernels and the copy back on the slot's
+  // stream; `end` waits for it and scatters the results into the caller's arrays
+  int (*host_chunk_begin)(cpmpc_solver* s, int slot, int64_t c0, int64_t Bc, int64_t g0, int64_t ld,
+                          const cpmpc_step_host_inputs& in, const cpmpc_step_host_outputs& out);
+  int (*host_chunk_end)(cpmpc_solver* s, int slot, int64_t ld, const cpmpc_step_host_outputs& out);
   // packed z [dim][B] (MapKey order) <-> workspace
   void (*pack_z)(cpmpc_solver* s, int64_t B, const void* z, hipStream_t stream);
   void (*unpack_z)(cpmpc_solver* s, int64_t B, void* z_out, hipStream_t stream);

@@ -17,7 +17,7 @@ using namespace cpmpc;
 static inline dim3 grid_for(int64_t threads) { return dim3((unsigned)((threads + 63) / 64)); }
 
 template <typename R, typename M>
-static void fill_args(const cpmpc_solver* s, int64_t B, SolverArgs<R, M>& a) {
+static void fill_args(const cpmpc_solver* s, int64_t B, SolverArgs<R, M>& a, int64_t col0 = 0) {
   const cpmpc_params& p = s->params;
   const cpmpc_solver_opts& o = s->opts;
   memset((void*)&a, 0, sizeof a);
@@ -73,20 +73,22 @@ static void fill_args(const cpmpc_solver* s, int64_t B, SolverArgs<R, M>& a) {
   a.rel_tol = (R)p.relative_exit_tol;
   a.fo_tol = (R)p.absolute_first_derivative_tol;
   a.mu_init = (R)p.equality_penalty_initial;
-  a.prev_B = s->prev_B;
+  // problems [col0, col0 + B) of the workspace: every field is [field][cap] with the problem index fastest, so the call
+  // works on a column range by offsetting the field bases (a chunk of a pipelined host-pointer step)
+  a.prev_B = s->prev_B - col0 < 0 ? 0 : (s->prev_B - col0 > B ? B : s->prev_B - col0);
   using V4 = typename VecT<R>::V4;
   using XVn = XV<R, M::NX>;
-  a.zx = (XVn*)s->zx;
-  a.zu = (R*)s->zu;
-  a.dzx = (XVn*)s->dzx;
-  a.dzu = (R*)s->dzu;
-  a.Phi = (XVn*)s->Phi;
-  a.Gam = (XVn*)s->Gam;
-  a.cs = (XVn*)s->cs;
-  a.Wk = (XVn*)s->Wk;
-  a.Tk = (V4*)s->Tk;
-  a.sc = (R*)s->sc;
-  a.ist = s->ist;
+  a.zx = (XVn*)s->zx + col0;
+  a.zu = (R*)s->zu + col0;
+  a.dzx = (XVn*)s->dzx + col0;
+  a.dzu = (R*)s->dzu + col0;
+  a.Phi = (XVn*)s->Phi + col0;
+  a.Gam = (XVn*)s->Gam + col0;
+  a.cs = (XVn*)s->cs + col0;
+  a.Wk = (XVn*)s->Wk + col0;
+  a.Tk = (V4*)s->Tk + col0;
+  a.sc = (R*)s->sc + col0;
+  a.ist = s->ist + col0;
   a.sin_table = (const R*)s->sin_table;
 }
 
@@ -172,9 +174,9 @@ static void launch_fused(const SolverArgs<R, M>& a, int L, int SP, int max_iters
 
 template <typename R, typename M>
 static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* in, const cpmpc_step_outputs* out,
-                           hipStream_t stream) {
+                           hipStream_t stream, int64_t col0, int slot) {
   SolverArgs<R, M> a;
-  fill_args<R, M>(s, B, a);
+  fill_args<R, M>(s, B, a, col0);
   a.x0 = (const R*)in->x0;
   a.dyn = (const R*)in->dyn;
   a.set_point = (const R*)in->set_point;
@@ -221,22 +223,23 @@ static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* 
     span_end(s, stream, &sp);
     int stage = 0;
     for (int done = s->stage_first; staged && done < total; done += s->stage_next, ++stage) {
-      int32_t* count = s->active + s->cap + (stage & 1);       // two counters: this compaction and the one before
-      a.prev_count = stage ? s->active + s->cap + ((stage - 1) & 1) : nullptr;
+      int32_t* const counters = s->active + s->cap + 2 * slot;  // a pair per host slot: chunks of a pipelined host step run concurrently
+      int32_t* count = counters + (stage & 1);                  // two counters: this compaction and the one before
+      a.prev_count = stage ? counters + ((stage - 1) & 1) : nullptr;
       a.prev_total = B;
       a.remaining = total - done;
       span_begin(s, CPMPC_KERNEL_FUSED, stream, &sp);
       const hipError_t memset_rc = hipMemsetAsync(count, 0, sizeof(int32_t), stream);
       hipLaunchKernelGGL((compact_active_kernel<M>), dim3((unsigned)((B + 1023) / 1024)), dim3(1024), 0, stream,
-                         (const int32_t*)(s->ist + (size_t)IS_STATUS * (size_t)s->cap),
-                         (const int32_t*)(s->ist + (size_t)IS_ITERS * (size_t)s->cap), total, B, s->active, count);
-      a.active_list = s->active;
+                         (const int32_t*)(a.ist + (size_t)IS_STATUS * (size_t)s->cap),
+                         (const int32_t*)(a.ist + (size_t)IS_ITERS * (size_t)s->cap), total, B, s->active + col0, count);
+      a.active_list = s->active + col0;
       a.active_count = count;
       const int k = (total - done < s->stage_next) ? (total - done) : s->stage_next;
       launch_fused<R, M>(a, s->S - 1, s->SP, k, stream);
       span_end(s, stream, &sp);  // the span is closed (its events recycled) before any early return
       if (memset_rc != hipSuccess) {
-        if (B > s->prev_B) s->prev_B = B;  // prepare has already shifted the warm start: keep the handle consistent
+        if (col0 + B > s->prev_B) s->prev_B = col0 + B;  // prepare has already shifted the warm start: keep the handle consistent
         return fail(CPMPC_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(memset_rc));
       }
     }
@@ -256,66 +259,109 @@ static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* 
   span_end(s, stream, &sp);
 
   HIP_TRY(hipGetLastError());
-  if (B > s->prev_B) s->prev_B = B;  // previous_solution_ = solver_->variables()  (optimization.cc:85), per problem
+  if (col0 + B > s->prev_B) s->prev_B = col0 + B;  // previous_solution_ = solver_->variables()  (optimization.cc:85), per problem
   return CPMPC_OK;
 }
 
-// A host-pointer step in two halves, so that several handles (the shards of cpmpc_sharded_*) can have their copies and
-// kernels in flight together: `begin` converts and uploads the inputs and queues the kernels and the copy back on the
-// handle's own stream; `end` waits for that stream and scatters the results into the caller's arrays.  The caller's
-// arrays are [field][ld] with this handle's B problems at columns [col0, col0 + B): ld = B, col0 = 0 for a plain call.
-struct HostStepLayout {
-  size_t off_u = 0, off_cost = 0, off_eq = 0, off_status = 0, off_iters = 0, off_sol = 0, off_pred = 0;  // bytes
+// ---- host-pointer steps: one chunk of problems through one staging slot ------------------------------------------------
+// Staging layout of a chunk of Bc problems, identical on the device and in the pinned mirror:
+//   [x0 | dyn? | set_point? | terminal_weights? | u | cost | eq | status | iters | solution? | predicted?]
+// (inputs first: one copy in; outputs after them: one copy back, the optional tails last)
+struct HostChunkLayout {
+  size_t off_dyn = 0, off_sp = 0, off_tw = 0, off_u = 0, off_cost = 0, off_eq = 0, off_status = 0, off_iters = 0, off_sol = 0,
+         off_pred = 0, end = 0;  // bytes
 };
 
 template <typename R, typename M>
-static HostStepLayout host_step_layout(const cpmpc_solver* s, int64_t B) {
-  // staging layout, identical on the device and in the pinned mirror:
-  //   [x0 | u | cost | eq | status | iters | solution | predicted]      (the optional tails last: one copy back)
-  const size_t nB = (size_t)B;
-  HostStepLayout L;
-  L.off_u = (size_t)M::NX * nB * sizeof(R);
-  L.off_cost = L.off_u + (size_t)s->N * nB * sizeof(R);
-  L.off_eq = L.off_cost + nB * sizeof(R);
-  L.off_status = L.off_eq + nB * sizeof(R);
+static HostChunkLayout host_chunk_layout(const cpmpc_solver* s, int64_t Bc, bool per_dyn, bool per_sp, bool per_tw) {
+  const size_t nB = (size_t)Bc, e = sizeof(R);
+  HostChunkLayout L;
+  L.off_dyn = (size_t)M::NX * nB * e;
+  L.off_sp = L.off_dyn + (per_dyn ? (size_t)M::NP * nB * e : 0);
+  L.off_tw = L.off_sp + (per_sp ? nB * e : 0);
+  L.off_u = L.off_tw + (per_tw ? (size_t)M::NX * nB * e : 0);
+  L.off_cost = L.off_u + (size_t)s->N * nB * e;
+  L.off_eq = L.off_cost + nB * e;
+  L.off_status = L.off_eq + nB * e;
   L.off_iters = L.off_status + nB * sizeof(int32_t);
   L.off_sol = (L.off_iters + nB * sizeof(int32_t) + 7) & ~(size_t)7;  // the real-typed tail starts 8-byte aligned
-  L.off_pred = L.off_sol + (size_t)s->dim * nB * sizeof(R);
+  L.off_pred = L.off_sol + (size_t)s->dim * nB * e;
+  L.end = L.off_pred + (size_t)M::NX * (size_t)s->N * nB * e;
   return L;
 }
 
+// rows of the caller's [rows][ld] double array, columns [g0, g0 + n)  <->  [rows][n] of R in the pinned mirror, the rows
+// spread over the library's worker threads (a 262 144-problem fp64 step returns 420 MB: one thread copies ~10 GB/s)
+template <typename R>
+struct RowCopy {
+  const double* src_d;
+  double* dst_d;
+  R* mir;
+  size_t ld, g0, n;
+  bool to_mirror;
+  static void run(int64_t r, void* ctx) {
+    const RowCopy& c = *(const RowCopy*)ctx;
+    R* m = c.mir + (size_t)r * c.n;
+    if (c.to_mirror) {
+      const double* src = c.src_d + (size_t)r * c.ld + c.g0;
+      for (size_t i = 0; i < c.n; ++i) m[i] = (R)src[i];
+    } else {
+      double* dst = c.dst_d + (size_t)r * c.ld + c.g0;
+      if constexpr (sizeof(R) == 8) memcpy(dst, m, c.n * 8);
+      else for (size_t i = 0; i < c.n; ++i) dst[i] = (double)m[i];
+    }
+  }
+};
+
+static bool host_ptr_is_pinned(const void* p) {
+  if (!p) return false;
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError();  // an ordinary (pageable) host pointer is reported as an error
+    return false;
+  }
+  return at.type == hipMemoryTypeHost;
+}
+
 template <typename R, typename M>
-static int step_host_begin(cpmpc_solver* s, int64_t B, const double* x0_host, int64_t ld, int64_t col0,
-                           const double* dyn_shared_host, double set_point, bool want_pred, bool want_sol) {
-  const size_t nB = (size_t)B;
-  const size_t n_pred = (size_t)M::NX * (size_t)s->N * nB;
-  const HostStepLayout L = host_step_layout<R, M>(s, B);
-  const size_t bytes = L.off_pred + n_pred * sizeof(R) + 64;
-  int rc = ensure_stage(s, bytes);
+static int host_chunk_begin(cpmpc_solver* s, int slot_i, int64_t c0, int64_t Bc, int64_t g0, int64_t ld,
+                            const cpmpc_step_host_inputs& in, const cpmpc_step_host_outputs& ho) {
+  const size_t nB = (size_t)Bc;
+  const bool per_dyn = in.dyn != nullptr, per_sp = in.set_point != nullptr, per_tw = in.terminal_weights != nullptr;
+  const bool want_pred = ho.predicted != nullptr, want_sol = ho.solution != nullptr;
+  const HostChunkLayout L = host_chunk_layout<R, M>(s, Bc, per_dyn, per_sp, per_tw);
+  int rc = ensure_slot(s, slot_i, L.end + 64);
   if (rc) return rc;
-  char* d_base = (char*)s->stage;
-  R* d_x0 = (R*)d_base;
-  R* h_x0 = (R*)s->pin;
-  const hipStream_t st = s->hstream;
+  HostSlot& sl = s->slot[slot_i];
+  char* d_base = (char*)sl.dev;
+  char* h_base = (char*)sl.pin;
+  const hipStream_t st = sl.stream;
   // from here on work is in flight on `st` that reads the pinned mirror and writes the staging buffer: every early
   // return drains the stream first, so that the next call never reuses them under a running copy
   auto bail = [&](int code) {
     (void)hipStreamSynchronize(st);
     return code;
   };
-  for (int t = 0; t < M::NX; ++t) {
-    const double* src = x0_host + (size_t)t * (size_t)ld + (size_t)col0;
-    R* dst = h_x0 + (size_t)t * nB;
-    for (size_t i = 0; i < nB; ++i) dst[i] = (R)src[i];
-  }
-  hipError_t e = hipMemcpyAsync(d_x0, h_x0, L.off_u, hipMemcpyHostToDevice, st);
+  auto stage_in = [&](const double* src, size_t off, size_t rows) {
+    RowCopy<R> c{src, nullptr, (R*)(h_base + off), (size_t)ld, (size_t)g0, nB, true};
+    if (rows * nB < 65536) for (size_t r = 0; r < rows; ++r) RowCopy<R>::run((int64_t)r, &c);
+    else host_parallel_for((int64_t)rows, &RowCopy<R>::run, &c);
+  };
+  stage_in(in.x0, 0, (size_t)M::NX);
+  if (per_dyn) stage_in(in.dyn, L.off_dyn, (size_t)M::NP);
+  if (per_sp) stage_in(in.set_point, L.off_sp, 1);
+  if (per_tw) stage_in(in.terminal_weights, L.off_tw, (size_t)M::NX);
+  hipError_t e = hipMemcpyAsync(d_base, h_base, L.off_u, hipMemcpyHostToDevice, st);
   if (e != hipSuccess) return bail(fail(CPMPC_ERR_HIP, "hipMemcpyAsync (inputs) failed: %s", hipGetErrorString(e)));
 
-  cpmpc_step_inputs in;
-  memset(&in, 0, sizeof in);
-  in.x0 = d_x0;
-  in.dyn_shared_host = dyn_shared_host;
-  in.set_point_shared = set_point;
+  cpmpc_step_inputs di;
+  memset(&di, 0, sizeof di);
+  di.x0 = d_base;
+  di.dyn_shared_host = per_dyn ? nullptr : in.dyn_shared;
+  di.dyn = per_dyn ? d_base + L.off_dyn : nullptr;
+  di.set_point_shared = in.set_point_shared;
+  di.set_point = per_sp ? d_base + L.off_sp : nullptr;
+  di.terminal_weights = per_tw ? d_base + L.off_tw : nullptr;
   cpmpc_step_outputs out;
   memset(&out, 0, sizeof out);
   out.u = d_base + L.off_u;
@@ -325,39 +371,70 @@ static int step_host_begin(cpmpc_solver* s, int64_t B, const double* x0_host, in
   out.final_cost = d_base + L.off_cost;
   out.final_eq_l1 = d_base + L.off_eq;
   out.solution = want_sol ? d_base + L.off_sol : nullptr;
-  rc = step_batch_impl<R, M>(s, B, &in, &out, st);
+  rc = step_batch_impl<R, M>(s, Bc, &di, &out, st, c0, slot_i);
   if (rc) return bail(rc);
-  // one copy back, from u to the end of what was asked for
-  const size_t end = want_pred ? L.off_pred + n_pred * sizeof(R)
-                               : (want_sol ? L.off_pred : L.off_iters + nB * sizeof(int32_t));
-  e = hipMemcpyAsync((char*)s->pin + L.off_u, d_base + L.off_u, end - L.off_u, hipMemcpyDeviceToHost, st);
-  if (e != hipSuccess) return bail(fail(CPMPC_ERR_HIP, "hipMemcpyAsync (outputs) failed: %s", hipGetErrorString(e)));
+
+  // Copy back.  A double handle whose real-typed output arrays the caller has pinned (hipHostMalloc / hipHostRegister /
+  // cpmpc_host_register) gets them by DMA straight into those arrays, no pass of the CPU over the data; everything else
+  // comes back into the mirror in one copy and is scattered by host_chunk_end.
+  bool direct = sizeof(R) == 8 && host_ptr_is_pinned(ho.u);
+  if (direct && want_pred && !host_ptr_is_pinned(ho.predicted)) direct = false;
+  if (direct && want_sol && !host_ptr_is_pinned(ho.solution)) direct = false;
+  if (direct) {
+    auto d2h = [&](double* dst, size_t off, size_t rows) -> hipError_t {
+      if (!dst) return hipSuccess;
+      return hipMemcpy2DAsync(dst + (size_t)g0, (size_t)ld * 8, d_base + off, nB * 8, nB * 8, rows, hipMemcpyDeviceToHost, st);
+    };
+    e = d2h(ho.u, L.off_u, (size_t)s->N);
+    if (e == hipSuccess) e = d2h(ho.solution, L.off_sol, (size_t)s->dim);
+    if (e == hipSuccess) e = d2h(ho.predicted, L.off_pred, (size_t)M::NX * (size_t)s->N);
+    if (e == hipSuccess)  // the small arrays still go through the mirror: cost, eq, status, iterations
+      e = hipMemcpyAsync(h_base + L.off_cost, d_base + L.off_cost, L.off_iters + nB * sizeof(int32_t) - L.off_cost,
+                         hipMemcpyDeviceToHost, st);
+  } else {
+    const size_t end = want_pred ? L.end : (want_sol ? L.off_pred : L.off_iters + nB * sizeof(int32_t));
+    e = hipMemcpyAsync(h_base + L.off_u, d_base + L.off_u, end - L.off_u, hipMemcpyDeviceToHost, st);
+  }
+  if (e == hipSuccess) e = hipEventRecord(sl.done, st);
+  if (e != hipSuccess) return bail(fail(CPMPC_ERR_HIP, "copy back of a host-pointer step failed: %s", hipGetErrorString(e)));
+  sl.busy = true;
+  sl.c0 = c0;
+  sl.Bc = Bc;
+  sl.g0 = g0;
+  sl.want_pred = want_pred;
+  sl.want_sol = want_sol;
+  sl.direct = direct;
+  // the layout depends on which per-problem inputs were given: remember it through the flags host_chunk_end recomputes from
+  sl.per_dyn = per_dyn;
+  sl.per_sp = per_sp;
+  sl.per_tw = per_tw;
   return CPMPC_OK;
 }
 
 template <typename R, typename M>
-static int step_host_end(cpmpc_solver* s, int64_t B, const cpmpc_step_host_outputs& ho, int64_t ld, int64_t col0) {
-  HIP_TRY(hipStreamSynchronize(s->hstream));
-  const size_t nB = (size_t)B;
-  const HostStepLayout L = host_step_layout<R, M>(s, B);
-  const char* h_base = (const char*)s->pin;
-  // rows of B scalars in the mirror -> rows of ld scalars in the caller's array, at column col0
+static int host_chunk_end(cpmpc_solver* s, int slot_i, int64_t ld, const cpmpc_step_host_outputs& ho) {
+  HostSlot& sl = s->slot[slot_i];
+  if (!sl.busy) return CPMPC_OK;
+  sl.busy = false;
+  HIP_TRY(hipEventSynchronize(sl.done));
+  const size_t nB = (size_t)sl.Bc;
+  const HostChunkLayout L = host_chunk_layout<R, M>(s, sl.Bc, sl.per_dyn, sl.per_sp, sl.per_tw);
+  char* h_base = (char*)sl.pin;
   auto fetch = [&](size_t off, double* hdst, size_t rows) {
     if (!hdst) return;
-    const R* h = (const R*)(h_base + off);
-    for (size_t r = 0; r < rows; ++r) {
-      double* dst = hdst + r * (size_t)ld + (size_t)col0;
-      const R* src = h + r * nB;
-      for (size_t i = 0; i < nB; ++i) dst[i] = (double)src[i];
-    }
+    RowCopy<R> c{nullptr, hdst, (R*)(h_base + off), (size_t)ld, (size_t)sl.g0, nB, false};
+    if (rows * nB < 65536) for (size_t r = 0; r < rows; ++r) RowCopy<R>::run((int64_t)r, &c);
+    else host_parallel_for((int64_t)rows, &RowCopy<R>::run, &c);
   };
-  fetch(L.off_u, ho.u, (size_t)s->N);
+  if (!sl.direct) {
+    fetch(L.off_u, ho.u, (size_t)s->N);
+    if (sl.want_sol) fetch(L.off_sol, ho.solution, (size_t)s->dim);
+    if (sl.want_pred) fetch(L.off_pred, ho.predicted, (size_t)M::NX * (size_t)s->N);
+  }
   fetch(L.off_cost, ho.final_cost, 1);
   fetch(L.off_eq, ho.final_eq_l1, 1);
-  fetch(L.off_sol, ho.solution, (size_t)s->dim);
-  fetch(L.off_pred, ho.predicted, (size_t)M::NX * (size_t)s->N);
-  if (ho.status) memcpy(ho.status + col0, h_base + L.off_status, nB * sizeof(int32_t));
-  if (ho.iterations) memcpy(ho.iterations + col0, h_base + L.off_iters, nB * sizeof(int32_t));
+  if (ho.status) memcpy(ho.status + sl.g0, h_base + L.off_status, nB * sizeof(int32_t));
+  if (ho.iterations) memcpy(ho.iterations + sl.g0, h_base + L.off_iters, nB * sizeof(int32_t));
   return CPMPC_OK;
 }
 
@@ -446,7 +523,7 @@ static int debug_read_impl(int which, unsigned long long* out) {
 
 #define CPMPC_DEFINE_ENGINE(NAME, R, M)                                                                              \
   const Engine* NAME() {                                                                                             \
-    static const Engine e = {&step_batch_impl<R, M>, &step_host_begin<R, M>, &step_host_end<R, M>, &pack_z_impl<R, M>, \
+    static const Engine e = {&step_batch_impl<R, M>, &host_chunk_begin<R, M>, &host_chunk_end<R, M>, &pack_z_impl<R, M>, \
                              &unpack_z_impl<R, M>,   &dynamics_impl<R, M>,   &rk4_impl<R, M>,      &sim_impl<R, M>,    \
                              &linearize_batch_impl<R, M>, &debug_read_impl};                                         \
     return &e;                                                                                                       \

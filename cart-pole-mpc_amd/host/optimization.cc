@@ -59,11 +59,18 @@ cpmpc_params ToCParams(const OptimizationParams& p) {
   throw std::runtime_error(text);
 }
 
-Optimization::Optimization(const OptimizationParams& params, std::size_t max_batch, int device)
+Optimization::Optimization(const OptimizationParams& params, std::size_t max_batch, int device, bool allow_long_horizon)
     : params_(params), max_batch_(max_batch) {
   const cpmpc_params c = ToC(params);
-  // fp64, like the reference.
-  const int rc = cpmpc_create(&c, nullptr, CPMPC_F64, static_cast<std::int64_t>(max_batch), device, &solver_);
+  cpmpc_create_info info{};
+  info.struct_size = sizeof info;
+  info.flags = allow_long_horizon ? CPMPC_CREATE_ALLOW_LONG_HORIZON : 0u;
+  info.dtype = CPMPC_F64;  // fp64, like the reference.
+  info.model = CPMPC_MODEL_SINGLE;
+  info.device = device;
+  info.max_batch = static_cast<std::int64_t>(max_batch);
+  info.params = &c;
+  const int rc = cpmpc_create_ex(&info, &solver_);
   if (rc != CPMPC_OK) Throw(rc);
 }
 
@@ -125,6 +132,40 @@ void Optimization::StepBatchInto(const double* states_soa, std::size_t B, const 
                                        predicted_states, status, iterations, final_cost, final_equality_l1);
   if (rc != CPMPC_OK) Throw(rc);
 }
+
+void Optimization::StepBatchInto(const double* states_soa, std::size_t B, const SingleCartPoleParams& dynamics_params,
+                                 double b_x_set_point, const PerProblemInputs& pp, double* u, double* predicted_states,
+                                 std::int32_t* status, std::int32_t* iterations, double* final_cost,
+                                 double* final_equality_l1, double* solution) {
+  if (states_soa == nullptr || B == 0) throw std::invalid_argument("StepBatch: states_soa must be [4][B], B >= 1");
+  if (B > max_batch_) throw std::invalid_argument("StepBatch: batch exceeds the capacity given at construction");
+  const auto dyn = dynamics_params.ToArray();
+  const cpmpc_step_host_inputs in = {states_soa, pp.dynamics_params ? nullptr : dyn.data(), pp.dynamics_params,
+                                     b_x_set_point, pp.set_points, pp.terminal_weights};
+  const cpmpc_step_host_outputs ho = {u, predicted_states, status, iterations, final_cost, final_equality_l1, solution};
+  const int rc = cpmpc_step_batch_host_in(solver_, static_cast<std::int64_t>(B), &in, &ho);
+  if (rc != CPMPC_OK) Throw(rc);
+}
+
+void Optimization::SetPreviousSolutionBatch(const std::vector<double>& z_soa, std::size_t B) {
+  if (B == 0 || z_soa.size() != Dim() * B) throw std::invalid_argument("SetPreviousSolutionBatch: z_soa must be [dim][B]");
+  const int rc = cpmpc_set_previous_solution_host(solver_, static_cast<std::int64_t>(B), z_soa.data());
+  if (rc != CPMPC_OK) Throw(rc);
+}
+
+std::vector<double> Optimization::GetSolutionBatch(std::size_t B) {
+  std::vector<double> z(Dim() * B);
+  const int rc = cpmpc_get_solution_host(solver_, static_cast<std::int64_t>(B), z.data());
+  if (rc != CPMPC_OK) Throw(rc);
+  return z;
+}
+
+void Optimization::SetHostChunk(std::size_t problems) {
+  const int rc = cpmpc_set_host_chunk(solver_, static_cast<std::int64_t>(problems));
+  if (rc != CPMPC_OK) Throw(rc);
+}
+
+std::size_t Optimization::Dim() const { return static_cast<std::size_t>(cpmpc_dim(solver_)); }
 
 BatchOptimizationOutputs Optimization::StepBatch(const std::vector<double>& states_soa,
                                                  const SingleCartPoleParams& dynamics_params,

@@ -76,12 +76,26 @@ struct BatchOptimizationOutputs {
   std::vector<double> final_equality_l1; // [B]
 };
 
+// Per-problem inputs of a batched step; a null pointer means "the shared argument of the call applies to every problem".
+// The reference has one parameter set, one set-point and one set of terminal weights per Optimization object
+// (optimization.hpp:73-108); a batch of controllers may differ in all three (domain randomisation, the UI's
+// per-controller cost / constraint toggles, viz/src/application.ts:279-342).
+struct PerProblemInputs {
+  const double* dynamics_params = nullptr;   // [9][B], SingleCartPoleParams field order (structs.hpp:8-41)
+  const double* set_points = nullptr;        // [B]
+  const double* terminal_weights = nullptr;  // [4][B] in state order; >= 0 a cost row, < 0 an equality row
+};
+
 // Hybrid multiple-shooting MPC (optimization.hpp:73-108), solved on the GPU.
 class Optimization {
  public:
   // Throws std::invalid_argument on the reference constructor's precondition failures
   // (optimization.cc:13-22) and std::runtime_error if no gfx950 device / library is usable.
-  explicit Optimization(const OptimizationParams& params, std::size_t max_batch = 1, int device = 0);
+  // allow_long_horizon: accept window_length * control_dt beyond 0.8 s (cpmpc_max_parity_horizon), where eliminating
+  // the states through the unstable plant no longer reproduces a full-space solve to 1e-5 on every cold start
+  // (include/cpmpc.h, CPMPC_CREATE_ALLOW_LONG_HORIZON); without it such parameters throw std::runtime_error.
+  explicit Optimization(const OptimizationParams& params, std::size_t max_batch = 1, int device = 0,
+                        bool allow_long_horizon = false);
   ~Optimization();
   Optimization(const Optimization&) = delete;
   Optimization& operator=(const Optimization&) = delete;
@@ -101,11 +115,25 @@ class Optimization {
                      double b_x_set_point, double* u, double* predicted_states, std::int32_t* status,
                      std::int32_t* iterations, double* final_cost, double* final_equality_l1);
 
+  // The general batched step: per-problem inputs (each optional) and, when `solution` is not null, the solution vectors
+  // z [dim][B] (MapKey order) as a further output.  Large batches run as a pipeline of chunks (include/cpmpc.h,
+  // cpmpc_set_host_chunk); output arrays pinned with cpmpc_host_register are written by DMA.
+  void StepBatchInto(const double* states_soa, std::size_t B, const SingleCartPoleParams& dynamics_params,
+                     double b_x_set_point, const PerProblemInputs& per_problem, double* u, double* predicted_states,
+                     std::int32_t* status, std::int32_t* iterations, double* final_cost, double* final_equality_l1,
+                     double* solution);
+
   // Discard previous initial guess, which will reset the problem (optimization.hpp:83).
   void Reset();
 
   // Set the previous solution, used as guess on the next iteration (optimization.hpp:86-89).
   void SetPreviousSolution(const std::vector<double>& guess);
+  // The same for B controllers: z_soa is [dim][B]; and its reverse (the warm start the next step will shift).
+  void SetPreviousSolutionBatch(const std::vector<double>& z_soa, std::size_t B);
+  [[nodiscard]] std::vector<double> GetSolutionBatch(std::size_t B);
+  // problems per chunk of a pipelined host-pointer step (0 = never split)
+  void SetHostChunk(std::size_t problems);
+  std::size_t Dim() const;
 
   const OptimizationParams& params() const noexcept { return params_; }
 

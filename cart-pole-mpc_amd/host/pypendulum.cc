@@ -138,14 +138,17 @@ PYBIND11_MODULE(pypendulum, m) {
 
   py::class_<Optimization>(m, "Optimization")
       .def(py::init<const OptimizationParams&>())
-      .def(py::init<const OptimizationParams&, std::size_t, int>(), py::arg("params"), py::arg("max_batch"),
-           py::arg("device") = 0)
+      .def(py::init<const OptimizationParams&, std::size_t, int, bool>(), py::arg("params"), py::arg("max_batch"),
+           py::arg("device") = 0, py::arg("allow_long_horizon") = false)
       .def("step", &Optimization::Step)
       .def("step_batch", &StepBatchArrays<Optimization>, py::arg("states"), py::arg("dynamics_params"),
            py::arg("b_x_set_point"), py::arg("want_predicted") = true)
       .def("step_batch_lists", &Optimization::StepBatch)  // round 2's element-by-element form, kept for comparison
       .def("reset", &Optimization::Reset)
-      .def("set_previous_solution", &Optimization::SetPreviousSolution);
+      .def("set_previous_solution", &Optimization::SetPreviousSolution)
+      .def("set_previous_solution_batch", &Optimization::SetPreviousSolutionBatch, py::arg("z_soa"), py::arg("batch"))
+      .def("get_solution_batch", &Optimization::GetSolutionBatch, py::arg("batch"))
+      .def("set_host_chunk", &Optimization::SetHostChunk, py::arg("problems"));
 
   py::class_<BatchArrays>(m, "BatchArrays")
       .def_readonly("batch", &BatchArrays::batch)
@@ -157,11 +160,14 @@ PYBIND11_MODULE(pypendulum, m) {
       .def_readonly("final_equality_l1", &BatchArrays::final_equality_l1);
 
   py::class_<ShardedOptimization>(m, "ShardedOptimization")
-      .def(py::init<const OptimizationParams&, std::size_t, const std::vector<int>&>(), py::arg("params"),
-           py::arg("max_batch"), py::arg("devices") = std::vector<int>{})
+      .def(py::init<const OptimizationParams&, std::size_t, const std::vector<int>&, bool>(), py::arg("params"),
+           py::arg("max_batch"), py::arg("devices") = std::vector<int>{}, py::arg("allow_long_horizon") = false)
       .def("step_batch", &StepBatchArrays<ShardedOptimization>, py::arg("states"), py::arg("dynamics_params"),
            py::arg("b_x_set_point"), py::arg("want_predicted") = true)
       .def("reset", &ShardedOptimization::Reset)
+      .def("set_previous_solution", &ShardedOptimization::SetPreviousSolution, py::arg("z_soa"), py::arg("batch"))
+      .def("get_solution", &ShardedOptimization::GetSolution, py::arg("batch"))
+      .def("previous_solution_batch", &ShardedOptimization::PreviousSolutionBatch)
       .def("num_shards", &ShardedOptimization::NumShards)
       .def("device_of_shard", &ShardedOptimization::DeviceOfShard)
       .def("shard_range", &ShardedOptimization::ShardRange);

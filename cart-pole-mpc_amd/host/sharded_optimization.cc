@@ -17,13 +17,54 @@ cpmpc_params ToCParams(const OptimizationParams& p);  // optimization.cc
 }
 
 ShardedOptimization::ShardedOptimization(const OptimizationParams& params, std::size_t max_batch,
-                                         const std::vector<int>& devices)
+                                         const std::vector<int>& devices, bool allow_long_horizon)
     : params_(params), max_batch_(max_batch) {
   const cpmpc_params c = ToCParams(params);
-  const int rc = cpmpc_sharded_create(&c, nullptr, CPMPC_F64, static_cast<std::int64_t>(max_batch),
-                                      devices.empty() ? nullptr : devices.data(), static_cast<int>(devices.size()),
-                                      &sharded_);
+  cpmpc_create_info info{};
+  info.struct_size = sizeof info;
+  info.flags = allow_long_horizon ? CPMPC_CREATE_ALLOW_LONG_HORIZON : 0u;
+  info.dtype = CPMPC_F64;
+  info.model = CPMPC_MODEL_SINGLE;
+  info.max_batch = static_cast<std::int64_t>(max_batch);
+  info.params = &c;
+  const int rc = cpmpc_sharded_create_ex(&info, devices.empty() ? nullptr : devices.data(),
+                                         static_cast<int>(devices.size()), &sharded_);
   if (rc != CPMPC_OK) ThrowSharded(rc);
+}
+
+void ShardedOptimization::StepBatchInto(const double* states_soa, std::size_t B,
+                                        const SingleCartPoleParams& dynamics_params, double b_x_set_point,
+                                        const PerProblemInputs& pp, double* u, double* predicted_states,
+                                        std::int32_t* status, std::int32_t* iterations, double* final_cost,
+                                        double* final_equality_l1, double* solution) {
+  if (states_soa == nullptr || B == 0) throw std::invalid_argument("StepBatch: states_soa must be [4][B], B >= 1");
+  if (B > max_batch_) throw std::invalid_argument("StepBatch: batch exceeds the capacity given at construction");
+  const auto dyn = dynamics_params.ToArray();
+  const cpmpc_step_host_inputs in = {states_soa, pp.dynamics_params ? nullptr : dyn.data(), pp.dynamics_params,
+                                     b_x_set_point, pp.set_points, pp.terminal_weights};
+  const cpmpc_step_host_outputs ho = {u, predicted_states, status, iterations, final_cost, final_equality_l1, solution};
+  const int rc = cpmpc_sharded_step_batch_host_in(sharded_, static_cast<std::int64_t>(B), &in, &ho);
+  if (rc != CPMPC_OK) ThrowSharded(rc);
+}
+
+void ShardedOptimization::SetPreviousSolution(const std::vector<double>& z_soa, std::size_t B) {
+  if (B == 0 || z_soa.size() != Dim() * B) throw std::invalid_argument("SetPreviousSolution: z_soa must be [dim][B]");
+  const int rc = cpmpc_sharded_set_previous_solution_host(sharded_, static_cast<std::int64_t>(B), z_soa.data());
+  if (rc != CPMPC_OK) ThrowSharded(rc);
+}
+
+std::vector<double> ShardedOptimization::GetSolution(std::size_t B) {
+  std::vector<double> z(Dim() * B);
+  const int rc = cpmpc_sharded_get_solution_host(sharded_, static_cast<std::int64_t>(B), z.data());
+  if (rc != CPMPC_OK) ThrowSharded(rc);
+  return z;
+}
+
+std::size_t ShardedOptimization::PreviousSolutionBatch() const noexcept {
+  return static_cast<std::size_t>(cpmpc_sharded_previous_solution_batch(sharded_));
+}
+std::size_t ShardedOptimization::Dim() const noexcept {
+  return static_cast<std::size_t>(cpmpc_dim(cpmpc_sharded_handle(sharded_, 0)));
 }
 
 ShardedOptimization::~ShardedOptimization() { cpmpc_sharded_destroy(sharded_); }

@@ -22,7 +22,7 @@ class ShardedOptimization {
   // devices: HIP device of each shard (a device may appear more than once); empty = every visible gfx950 device.
   // max_batch is the TOTAL number of controllers.  Throws like Optimization's constructor.
   explicit ShardedOptimization(const OptimizationParams& params, std::size_t max_batch,
-                               const std::vector<int>& devices = {});
+                               const std::vector<int>& devices = {}, bool allow_long_horizon = false);
   ~ShardedOptimization();
   ShardedOptimization(const ShardedOptimization&) = delete;
   ShardedOptimization& operator=(const ShardedOptimization&) = delete;
@@ -34,8 +34,22 @@ class ShardedOptimization {
   void StepBatchInto(const double* states_soa, std::size_t B, const SingleCartPoleParams& dynamics_params,
                      double b_x_set_point, double* u, double* predicted_states, std::int32_t* status,
                      std::int32_t* iterations, double* final_cost, double* final_equality_l1);
+  // The general step: per-problem parameters / set-points / terminal rows (each optional) and the solution vectors
+  // z [dim][B] as a further output (optimization.hpp: PerProblemInputs).
+  void StepBatchInto(const double* states_soa, std::size_t B, const SingleCartPoleParams& dynamics_params,
+                     double b_x_set_point, const PerProblemInputs& per_problem, double* u, double* predicted_states,
+                     std::int32_t* status, std::int32_t* iterations, double* final_cost, double* final_equality_l1,
+                     double* solution);
   // Optimization::Reset on every shard.
   void Reset();
+  // Optimization::SetPreviousSolution for B controllers (optimization.hpp:86-89): z_soa is [dim][B]; replaces every
+  // shard's warm start.  GetSolution(B) is its reverse for the first B controllers that hold one.
+  void SetPreviousSolution(const std::vector<double>& z_soa, std::size_t B);
+  [[nodiscard]] std::vector<double> GetSolution(std::size_t B);
+  // controllers [0, n) hold a previous solution.  A step with another batch size than the last one hands the warm start
+  // over to the new split first (include/cpmpc.h: "Warm starts and the batch size"); nothing is ever misaligned.
+  std::size_t PreviousSolutionBatch() const noexcept;
+  std::size_t Dim() const noexcept;
 
   std::size_t NumShards() const noexcept;
   int DeviceOfShard(std::size_t shard) const noexcept;

@@ -120,6 +120,36 @@ int cpmpc_create(const cpmpc_params* params, const cpmpc_solver_opts* opts /*nul
                  int64_t max_batch, int device, cpmpc_solver** out);
 void cpmpc_destroy(cpmpc_solver* s);
 
+/* The same constructor with its arguments in a size-versioned struct, plus what the positional forms cannot express:
+ *   flags      CPMPC_CREATE_ALLOW_LONG_HORIZON: accept a horizon window_length * control_dt beyond
+ *              cpmpc_max_parity_horizon().  cpmpc_create / cpmpc_create_model return CPMPC_ERR_UNSUPPORTED for those:
+ *              the QP is solved by eliminating the states through the shooting recursion, and through more than
+ *              ~0.8 s of the default pole (unstable at e^{6.3 t}) that loses about three digits per QP against a
+ *              full-space KKT solve with pivoting -- measured at window_length 160, control_dt 0.01: after three
+ *              iterations from a cold start 0.5 % of the problems are beyond 1e-5 of the CPU check (worst 0.4), where
+ *              window_length 80 keeps every problem within 3e-6.  With the flag such a horizon is solved as it always
+ *              was; warm-started closed loops are not affected in practice, cold starts far from the optimum are.
+ *   opts_size  sizeof(cpmpc_solver_opts) as the CALLER was compiled (0 = this header's).  Option fields are only ever
+ *              appended; a caller built against an earlier header passes its shorter size and keeps the library's
+ *              defaults for the fields it does not know (full_step_below was appended in round 3).  Always start from
+ *              cpmpc_default_solver_opts: a zero-initialised struct is NOT the defaults. */
+#define CPMPC_CREATE_ALLOW_LONG_HORIZON 1u
+typedef struct cpmpc_create_info {
+  uint32_t struct_size; /* = sizeof(cpmpc_create_info) */
+  uint32_t flags;
+  int32_t dtype;  /* CPMPC_F32 / CPMPC_F64 */
+  int32_t model;  /* CPMPC_MODEL_* */
+  int32_t device; /* HIP device */
+  int32_t reserved; /* 0 */
+  int64_t max_batch;
+  const cpmpc_params* params;
+  const cpmpc_solver_opts* opts; /* nullable */
+  uint64_t opts_size;
+} cpmpc_create_info;
+int cpmpc_create_ex(const cpmpc_create_info* info, cpmpc_solver** out);
+/* seconds: the longest horizon held to 1e-5 of the CPU check on every problem (0.8) */
+double cpmpc_max_parity_horizon(void);
+
 /* 2: register-resident linearisation compiled for this spacing (1,2,4,5,8,10,20); 1: served by the generic
  * run-time-spacing kernel; 0: not a valid spacing */
 int cpmpc_supported_state_spacing(int spacing);
@@ -197,6 +227,30 @@ typedef struct cpmpc_step_host_outputs {
 } cpmpc_step_host_outputs;
 int cpmpc_step_batch_host_ex(cpmpc_solver* s, int64_t B, const double* x0_host, const double* dyn_shared_host,
                              double set_point, const cpmpc_step_host_outputs* out);
+/* The general form: cpmpc_step_inputs with HOST double arrays, including the per-problem parameters, set-points and
+ * terminal rows (optimization.cc:236-267).  Exactly one of dyn_shared / dyn must be non-NULL. */
+typedef struct cpmpc_step_host_inputs {
+  const double* x0;               /* [4][B] */
+  const double* dyn_shared;       /* [9] shared by the batch, or NULL */
+  const double* dyn;              /* [9][B] per problem, or NULL */
+  double set_point_shared;        /* used if set_point is NULL */
+  const double* set_point;        /* [B] or NULL */
+  const double* terminal_weights; /* [4][B] (>= 0 cost row, < 0 equality row) or NULL */
+} cpmpc_step_host_inputs;
+int cpmpc_step_batch_host_in(cpmpc_solver* s, int64_t B, const cpmpc_step_host_inputs* in,
+                             const cpmpc_step_host_outputs* out);
+/* How the host-pointer calls run (round 4).  A step of more than 1.5 x `problems` problems (default 32 768) is split into
+ * chunks that rotate through three staging slots on three streams: while the CPU scatters chunk k's results into the
+ * caller's arrays (on the library's worker threads; CPMPC_HOST_THREADS, default 8), chunk k+1 is copying back and chunk
+ * k+2 is in the kernels.  Results are bitwise those of the unsplit call (a problem's arithmetic does not depend on its
+ * neighbours).  0 = never split.  Measured at B = 262 144, fp64: see INTEGRATION.md section 4. */
+int cpmpc_set_host_chunk(cpmpc_solver* s, int64_t problems);
+/* Pin a host array the caller keeps (page-locks it and maps it for DMA: hipHostRegister).  When the real-typed output
+ * arrays (u, predicted, solution) of a CPMPC_F64 handle's host-pointer step are pinned -- by this call, hipHostMalloc or
+ * hipHostRegister -- the results are copied by DMA straight into them and no CPU pass over the data remains.  The array
+ * must stay allocated until cpmpc_host_unregister. */
+int cpmpc_host_register(void* ptr, uint64_t bytes);
+int cpmpc_host_unregister(void* ptr);
 int cpmpc_set_previous_solution_host(cpmpc_solver* s, int64_t B, const double* z_host);
 int cpmpc_get_solution_host(cpmpc_solver* s, int64_t B, double* z_host);
 
@@ -272,6 +326,8 @@ typedef struct cpmpc_sharded cpmpc_sharded;
 /* devices == NULL: every visible gfx950 device, one shard each (n_devices ignored).  max_batch is the TOTAL batch. */
 int cpmpc_sharded_create(const cpmpc_params* params, const cpmpc_solver_opts* opts /*nullable*/, int dtype,
                          int64_t max_batch, const int* devices, int n_devices, cpmpc_sharded** out);
+/* the same from a cpmpc_create_info (its `device` is ignored, its max_batch is the TOTAL batch): any model, creation flags */
+int cpmpc_sharded_create_ex(const cpmpc_create_info* info, const int* devices, int n_devices, cpmpc_sharded** out);
 void cpmpc_sharded_destroy(cpmpc_sharded* s);
 int cpmpc_sharded_num_shards(const cpmpc_sharded* s);
 int cpmpc_sharded_device(const cpmpc_sharded* s, int shard);          /* HIP device of a shard; -1 if out of range */
@@ -279,13 +335,43 @@ cpmpc_solver* cpmpc_sharded_handle(cpmpc_sharded* s, int shard);      /* the sha
 /* columns [*lo, *hi) of a B-problem batch that shard `shard` solves */
 int cpmpc_sharded_range(const cpmpc_sharded* s, int shard, int64_t B, int64_t* lo, int64_t* hi);
 int cpmpc_sharded_reset(cpmpc_sharded* s);                             /* Optimization::Reset on every shard */
-/* cpmpc_step_batch_host_ex over all shards: HOST arrays in the global layouts ([4][B] in, [N][B] etc. out). */
+
+/* Warm starts and the batch size.  Which shard owns a column depends on B, so the shards' previous solutions are tied to
+ * the B of the call that produced them.  The rule, checked on every step / set / get:
+ *   - a call with the same B as the last one uses the warm starts in place;
+ *   - a call with another B first HANDS THE WARM START OVER to the new split (the solutions of the warm columns are
+ *     gathered on the root device, every shard is reset, and each receives the columns it owns under the new B):
+ *     columns [0, min(B, n)) stay warm, n = cpmpc_sharded_previous_solution_batch(); columns beyond B are dropped
+ *     (a single handle would keep them: include/cpmpc.h, cpmpc_previous_solution_batch), new columns start cold;
+ *   - a step that fails part-way resets every shard (no mixture of old and new solutions survives).
+ * Never a silent misalignment.  The hand-over is synchronous and costs one gather + one scatter of [dim][n] scalars. */
+int64_t cpmpc_sharded_previous_solution_batch(const cpmpc_sharded* s);
+/* Optimization::SetPreviousSolution over all shards (optimization.hpp:86-89): z [dim][B] on the ROOT device in the
+ * handle's dtype (asynchronous on `stream`, a stream of the root device), or HOST doubles.  Replaces every warm start. */
+int cpmpc_sharded_set_previous_solution(cpmpc_sharded* s, int64_t B, const void* z, void* stream);
+int cpmpc_sharded_set_previous_solution_host(cpmpc_sharded* s, int64_t B, const double* z_host);
+/* The warm start of columns [0, B), B <= cpmpc_sharded_previous_solution_batch() (what the next step reports as
+ * OptimizationOutputs::previous_solution, optimization.cc:84): z_out [dim][B]. */
+int cpmpc_sharded_get_solution(cpmpc_sharded* s, int64_t B, void* z_out, void* stream);
+int cpmpc_sharded_get_solution_host(cpmpc_sharded* s, int64_t B, double* z_host);
+
+/* cpmpc_step_batch_host_in over all shards: HOST arrays in the global layouts ([4][B] in, [N][B] etc. out), per-problem
+ * parameters / set-points / terminal rows included; every shard's chunks are in flight together (cpmpc_set_host_chunk
+ * on a shard's handle changes its chunk size). */
+int cpmpc_sharded_step_batch_host_in(cpmpc_sharded* s, int64_t B, const cpmpc_step_host_inputs* in,
+                                     const cpmpc_step_host_outputs* out);
+/* shared parameters only (round 3's form) */
 int cpmpc_sharded_step_batch_host(cpmpc_sharded* s, int64_t B, const double* x0_host, const double* dyn_shared_host,
                                   double set_point, const cpmpc_step_host_outputs* out);
-/* cpmpc_step_batch over all shards with the data resident in HBM: x0 [4][B] and every non-NULL output ([N][B] u,
- * [N][4][B] predicted, [B] status / iterations / final_cost / final_eq_l1; guess / ls_evals / solution are not gathered)
- * live on the ROOT device (shard 0's), in the handle's dtype.  Asynchronous on `stream` (a stream of the root
- * device): slices travel to and from the other shards' devices by peer copies ordered with events. */
+/* cpmpc_step_batch over all shards with the data resident in HBM: every array of `in` (x0 [4][B]; dyn [9][B], set_point
+ * [B], terminal_weights [4][B] when given) and every non-NULL output ([N][B] u, [N][4][B] predicted, [B] status /
+ * iterations / ls_evals / final_cost / final_eq_l1, [dim][B] guess / solution) lives on the ROOT device (shard 0's), in
+ * the handle's dtype.  Asynchronous on `stream` (a stream of the root device): slices travel to and from the other
+ * shards' devices by peer copies ordered with events; on a failure part-way the call waits for the copies of the shards
+ * already started before it returns the error. */
+int cpmpc_sharded_step_batch_ex(cpmpc_sharded* s, int64_t B, const cpmpc_step_inputs* in,
+                                const cpmpc_step_outputs* out, void* stream);
+/* shared parameters only (round 3's form) */
 int cpmpc_sharded_step_batch(cpmpc_sharded* s, int64_t B, const void* x0, const double* dyn_shared_host,
                              double set_point, const cpmpc_step_outputs* out, void* stream);
 

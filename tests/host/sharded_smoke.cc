@@ -86,6 +86,116 @@ int main(int argc, char** argv) {
     EXPECT(same_bits(a.u, b.u), "B=%zu: u differs after Reset", B);
     std::printf("B=%zu over %zu shard(s): bitwise equal to the single handle (3 ticks + reset)\n", B, n);
   }
+  // ---- warm starts across a CHANGED batch size (round 4): the split of a batch depends on its size, so a sharded
+  // optimizer hands the warm start over to the new split; a single handle keeps it in place.  Growing and shrinking
+  // batches must stay bitwise equal to the single handle on the columns that are warm in both.
+  {
+    const std::size_t Bmax = 4133;
+    std::mt19937_64 rng(99);
+    std::uniform_real_distribution<double> U(-1.0, 1.0);
+    std::vector<double> x_all(4 * Bmax);
+    for (std::size_t i = 0; i < Bmax; ++i) {
+      x_all[0 * Bmax + i] = 0.6 * U(rng);
+      x_all[1 * Bmax + i] = M_PI * U(rng);
+      x_all[2 * Bmax + i] = U(rng);
+      x_all[3 * Bmax + i] = 3.0 * U(rng);
+    }
+    auto first_columns = [&](std::size_t B) {  // [4][B] of the first B problems
+      std::vector<double> x(4 * B);
+      for (int t = 0; t < 4; ++t) std::memcpy(&x[t * B], &x_all[t * Bmax], B * sizeof(double));
+      return x;
+    };
+    Optimization single(params, Bmax);
+    ShardedOptimization sharded(params, Bmax, devices);
+    const std::size_t n = sharded.NumShards();
+    // 3000 cold -> 4133 (first 3000 warm, the rest cold) -> 2000 (all warm) -> 2000 again
+    for (const std::size_t B : {std::size_t{3000}, std::size_t{4133}, std::size_t{2000}, std::size_t{2000}}) {
+      const std::vector<double> x = first_columns(B);
+      const BatchOptimizationOutputs a = single.StepBatch(x, dyn, 0.02);
+      const BatchOptimizationOutputs b = sharded.StepBatch(x, dyn, 0.02);
+      EXPECT(same_bits(a.u, b.u) && same_bits(a.iterations, b.iterations) && same_bits(a.final_cost, b.final_cost),
+             "hand-over: B=%zu differs between one handle and %zu shards", B, n);
+      EXPECT(sharded.PreviousSolutionBatch() == B, "hand-over: %zu controllers warm after a step of %zu",
+             sharded.PreviousSolutionBatch(), B);
+    }
+    // the warm starts themselves, read back: [dim][2000] of both
+    EXPECT(same_bits(single.GetSolutionBatch(2000), sharded.GetSolution(2000)), "GetSolution differs after the hand-overs");
+    // growing again: the single handle still holds columns 2000.. from the 4133-step, the sharded one dropped them
+    // (documented): the first 2000 columns are warm in both and must agree, column by column
+    {
+      const std::vector<double> x = first_columns(Bmax);
+      const BatchOptimizationOutputs a = single.StepBatch(x, dyn, 0.02);
+      const BatchOptimizationOutputs b = sharded.StepBatch(x, dyn, 0.02);
+      bool same = true;
+      for (std::size_t k = 0; k < N && same; ++k)
+        same = std::memcmp(&a.u[k * Bmax], &b.u[k * Bmax], 2000 * sizeof(double)) == 0;
+      EXPECT(same, "hand-over: the columns that were warm in both differ after growing the batch again");
+    }
+    // SetPreviousSolution: a solution taken from one optimizer warm-starts a FRESH one of the other kind identically
+    {
+      const std::size_t B = 2500;
+      const std::vector<double> z = single.GetSolutionBatch(B);
+      Optimization single2(params, Bmax);
+      ShardedOptimization sharded2(params, Bmax, devices);
+      single2.SetPreviousSolutionBatch(z, B);
+      sharded2.SetPreviousSolution(z, B);
+      EXPECT(same_bits(sharded2.GetSolution(B), z), "SetPreviousSolution / GetSolution is not a round trip");
+      const std::vector<double> x = first_columns(B);
+      const BatchOptimizationOutputs a = single2.StepBatch(x, dyn, -0.03);
+      const BatchOptimizationOutputs b = sharded2.StepBatch(x, dyn, -0.03);
+      EXPECT(same_bits(a.u, b.u) && same_bits(a.status, b.status), "SetPreviousSolution: warm-started steps differ");
+    }
+    std::printf("warm-start hand-over across batch sizes 3000 -> 4133 -> 2000 -> 4133 and Set/GetSolution: bitwise equal (%zu shards)\n", n);
+
+    // ---- per-problem parameters, set-points and terminal rows through the sharded host call, and the chunk pipeline ----
+    {
+      const std::size_t B = 3001;
+      const std::vector<double> x = first_columns(B);
+      std::vector<double> dynp(9 * B), sp(B), tw(4 * B);
+      const auto d0 = dyn.ToArray();
+      for (std::size_t i = 0; i < B; ++i) {
+        for (int f = 0; f < 9; ++f) dynp[f * B + i] = d0[f] * (1.0 + 0.1 * U(rng));
+        sp[i] = 0.2 * U(rng);
+        tw[0 * B + i] = 100.0 + 50.0 * U(rng);          // b_x: always a cost row
+        tw[1 * B + i] = (i % 3 == 0) ? 40.0 : -1.0;     // theta: a cost row for every third controller, else an equality
+        tw[2 * B + i] = -1.0;
+        tw[3 * B + i] = (i % 5 == 0) ? 5.0 : -1.0;
+      }
+      const PerProblemInputs pp{dynp.data(), sp.data(), tw.data()};
+      const std::size_t dim = single.Dim();
+      auto run = [&](auto& opt, std::vector<double>& u, std::vector<double>& pred, std::vector<std::int32_t>& st,
+                     std::vector<double>& z) {
+        u.assign(N * B, 0.0);
+        pred.assign(4 * N * B, 0.0);
+        st.assign(B, 0);
+        z.assign(dim * B, 0.0);
+        opt.StepBatchInto(x.data(), B, dyn, 0.0, pp, u.data(), pred.data(), st.data(), nullptr, nullptr, nullptr, z.data());
+      };
+      std::vector<double> u1, p1, z1, u2, p2, z2, u3, p3, z3;
+      std::vector<std::int32_t> s1, s2, s3;
+      Optimization a(params, B);
+      a.SetHostChunk(0);  // one piece
+      run(a, u1, p1, s1, z1);
+      Optimization c(params, B);
+      c.SetHostChunk(256);  // twelve chunks through three slots
+      run(c, u3, p3, s3, z3);
+      ShardedOptimization b(params, B, devices);
+      run(b, u2, p2, s2, z2);
+      EXPECT(same_bits(u1, u3) && same_bits(p1, p3) && same_bits(s1, s3) && same_bits(z1, z3),
+             "per-problem inputs: the chunked host step differs from the unsplit one");
+      EXPECT(same_bits(u1, u2) && same_bits(p1, p2) && same_bits(s1, s2) && same_bits(z1, z2),
+             "per-problem inputs: %zu shards differ from one handle", b.NumShards());
+      // and the per-problem inputs were really used: against the shared-parameter solve most controls must differ
+      std::vector<double> u0(N * B);
+      Optimization d(params, B);
+      d.StepBatchInto(x.data(), B, dyn, 0.0, PerProblemInputs{}, u0.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+      std::size_t differ = 0;
+      for (std::size_t i = 0; i < B; ++i) differ += (u0[i] != u1[i]);
+      EXPECT(differ > B / 2, "per-problem inputs had no effect (%zu of %zu first controls differ)", differ, B);
+      std::printf("per-problem dyn / set-point / terminal rows: chunked == unsplit == %zu shards, bitwise\n", b.NumShards());
+    }
+  }
+
   // capacity and argument errors surface as exceptions, like Optimization's
   bool threw = false;
   try {

@@ -50,6 +50,19 @@ def test_launcher_spawns_world_of_two(monkeypatch):
     assert line["per_rank"] == [[0.0, 0.0], [1.0, 10.0]]      # every rank's own timings reach the line
 
 
+def test_launcher_spawns_world_of_eight(monkeypatch):
+    """The driver's scaling run is `bench.py --gpus 8`: eight ranks, one gather to rank 0, eight entries in every per-rank
+    list.  (On the GPU box at most six processes may use the card, so the eight-rank form is exercised here, on gloo.)"""
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    rc, out0 = bench.launch_ranks(8, ["--gpus", "8", "--batch", "32"], n_devices=8, script=STUB, timeout=600)
+    assert rc == 0, out0
+    line = json.loads(bench.last_json_line(out0))
+    assert line["n_gpus"] == 8 and line["world_size_seen"] == 8
+    assert line["gathered"] == [4, 256] and line["in_global_order"]
+    assert line["local_ranks"] == list(range(8)) and line["max_rank"] == 7.0
+    assert len(line["per_rank"]) == 8 and line["per_rank"][7] == [7.0, 70.0]
+
+
 def test_a_rank_that_dies_ends_the_run_at_once(monkeypatch):
     """a non-zero rank that dies early must not leave rank 0 waiting in a collective until its timeout
     (the stub's other ranks sleep 120 s): the launcher polls all ranks, kills the rest and returns that exit code."""

@@ -42,6 +42,8 @@ def test_header_is_plain_c_and_struct_layouts_match(lib, pkg, tmp_path):
         "cpmpc_step_inputs": [f for f, _ in pkg.capi.StepInputs._fields_],
         "cpmpc_step_outputs": [f for f, _ in pkg.capi.StepOutputs._fields_],
         "cpmpc_step_host_outputs": [f for f, _ in pkg.capi.StepHostOutputs._fields_],
+        "cpmpc_step_host_inputs": [f for f, _ in pkg.capi.StepHostInputs._fields_],
+        "cpmpc_create_info": [f for f, _ in pkg.capi.CreateInfo._fields_],
     }
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "cpmpc.h"', "int main(void) {"]
     for st, fs in fields.items():
@@ -56,7 +58,8 @@ def test_header_is_plain_c_and_struct_layouts_match(lib, pkg, tmp_path):
     got = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
     mirrors = {"cpmpc_params": pkg.capi.Params, "cpmpc_solver_opts": pkg.capi.SolverOpts,
                "cpmpc_step_inputs": pkg.capi.StepInputs, "cpmpc_step_outputs": pkg.capi.StepOutputs,
-               "cpmpc_step_host_outputs": pkg.capi.StepHostOutputs}
+               "cpmpc_step_host_outputs": pkg.capi.StepHostOutputs, "cpmpc_step_host_inputs": pkg.capi.StepHostInputs,
+               "cpmpc_create_info": pkg.capi.CreateInfo}
     for st, cls in mirrors.items():
         assert int(got[st]) == C.sizeof(cls), st
         for f, _ in cls._fields_:
@@ -131,6 +134,43 @@ def test_fails_loudly_without_a_gpu(lib, pkg):
                                     None) == pkg.capi.ERR_NO_DEVICE
     with pytest.raises(pkg.CpmpcError):
         pkg.capi.check(rc)
+
+
+def test_long_horizons_are_refused_unless_asked_for(lib, pkg):
+    """window_length * control_dt beyond cpmpc_max_parity_horizon() (0.8 s) is CPMPC_ERR_UNSUPPORTED from every positional
+    constructor, with the flag that lifts it named in the message; cpmpc_create_ex with the flag gets as far as the
+    device check.  The versioned structs reject a wrong struct_size / opts_size.  (No device is needed for any of it.)"""
+    assert lib.cpmpc_max_parity_horizon() == pytest.approx(0.8)
+    h = C.c_void_p()
+    for over in (dict(window_length=160), dict(window_length=100), dict(control_dt=0.05)):
+        p = pkg.capi.default_params(**over)
+        assert lib.cpmpc_create(C.byref(p), None, pkg.capi.F64, 8, 0, C.byref(h)) == pkg.capi.ERR_UNSUPPORTED, over
+        assert b"CPMPC_CREATE_ALLOW_LONG_HORIZON" in lib.cpmpc_last_error()
+        assert lib.cpmpc_sharded_create(C.byref(p), None, pkg.capi.F64, 8, None, 0, C.byref(h)) in (
+            pkg.capi.ERR_UNSUPPORTED, pkg.capi.ERR_NO_DEVICE)
+    ok = pkg.capi.default_params(window_length=80)
+    assert lib.cpmpc_create(C.byref(ok), None, pkg.capi.F64, 8, 0, C.byref(h)) in (pkg.capi.OK, pkg.capi.ERR_NO_DEVICE)
+    if h.value:
+        lib.cpmpc_destroy(h)
+    p = pkg.capi.default_params(window_length=160)
+
+    def info(**kw):
+        i = pkg.capi.CreateInfo(struct_size=C.sizeof(pkg.capi.CreateInfo), flags=0, dtype=pkg.capi.F64, model=0, device=0,
+                                reserved=0, max_batch=8, params=C.pointer(p), opts=None, opts_size=0)
+        for k, v in kw.items():
+            setattr(i, k, v)
+        return i
+    h = C.c_void_p()
+    assert lib.cpmpc_create_ex(C.byref(info()), C.byref(h)) == pkg.capi.ERR_UNSUPPORTED
+    rc = lib.cpmpc_create_ex(C.byref(info(flags=pkg.capi.CREATE_ALLOW_LONG_HORIZON)), C.byref(h))
+    assert rc in (pkg.capi.OK, pkg.capi.ERR_NO_DEVICE)   # past the horizon check
+    if h.value:
+        lib.cpmpc_destroy(h)
+    assert lib.cpmpc_create_ex(C.byref(info(struct_size=12)), C.byref(h)) == pkg.capi.ERR_INVALID_ARG
+    assert lib.cpmpc_create_ex(C.byref(info(flags=0x80)), C.byref(h)) == pkg.capi.ERR_INVALID_ARG
+    o = pkg.capi.default_solver_opts()
+    assert lib.cpmpc_create_ex(C.byref(info(flags=1, opts=C.pointer(o), opts_size=C.sizeof(o) + 8)),
+                               C.byref(h)) == pkg.capi.ERR_INVALID_ARG
 
 
 def test_product_does_not_import_the_oracle():

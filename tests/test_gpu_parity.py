@@ -645,13 +645,22 @@ def test_profiling_counts_launches(pkg):
                                   dict(window_length=80, state_spacing=5, max_iterations=3)])
 def test_long_horizons_fused(pkg, orc, over):
     """Horizons of 80 and 160 steps: 8 and 16 lanes per problem in the fused kernel (generic group traffic).
-    Eliminating the states through 16 intervals of an unstable plant (1.6 s) is worse conditioned than the
-    oracle's full-space KKT solve; with the terminal multipliers refined through the factored operator every lane
-    of both pipelines stays within 1e-5 of the oracle at N = 80 and N = 160 (before: 99 % at N = 160, worst 2e-4)."""
+    N = 80 (0.8 s, the longest horizon the library accepts without being asked, cpmpc_max_parity_horizon): EVERY lane of
+    both pipelines within 1e-5 of the oracle.  N = 160 (1.6 s) must be asked for (CPMPC_CREATE_ALLOW_LONG_HORIZON):
+    eliminating the states through 16 intervals of an unstable plant loses about three digits per QP against the
+    oracle's full-space KKT solve, and at batch scale 0.5 % of cold starts end beyond 1e-5 (profiles/r04_parity_sweep.json;
+    neither wider accumulation of the terminal system nor more refinement passes change that); on
+    these 96 lanes at most two may, and those are handed to the extended-precision build of the oracle."""
     rng = np.random.default_rng(11)
     x0 = random_states(rng, 96)
     x0[1, ::2] = np.pi / 2 + rng.uniform(-0.3, 0.3, 48)
-    opt = pkg.BatchOptimization(pkg.default_params(**over), max_batch=96, dtype=torch.float64, device=0)
+    long_h = over["window_length"] > 80
+    if long_h:  # refused unless asked for, with the reason in the message
+        with pytest.raises(pkg.CpmpcError) as exc:
+            pkg.BatchOptimization(pkg.default_params(**over), max_batch=96, dtype=torch.float64, device=0)
+        assert exc.value.code == pkg.capi.ERR_UNSUPPORTED and "ALLOW_LONG_HORIZON" in str(exc.value)
+    opt = pkg.BatchOptimization(pkg.default_params(**over), max_batch=96, dtype=torch.float64, device=0,
+                                allow_long_horizon=long_h)
     assert opt.pipeline() == "fused"
     out = opt.step(T(x0), DYN_UI, 0.0)
     u_cpu, _, st_cpu, it_cpu, _ = orc.step_batch_cold(orc.default_opt_params(**over), DYN_UI, 0.0, x0)
@@ -663,7 +672,7 @@ def test_long_horizons_fused(pkg, orc, over):
     # an ulp -- and is then handed to the extended-precision build of the oracle: the GPU must be as close to that
     # answer as the double oracle is (x2), i.e. the distance is the problem's rounding sensitivity, not a defect
     over_bar = np.nonzero(err >= 1e-5)[0]
-    assert over_bar.size <= 2 and err.max() < 1e-4, np.sort(err)[-5:]
+    assert over_bar.size <= (2 if long_h else 0) and err.max() < 1e-4, np.sort(err)[-5:]
     if over_bar.size:
         u_ld, _, _, _, _ = orc.step_batch_cold_ld(orc.default_opt_params(**over), DYN_UI, 0.0, x0[:, over_bar])
         e_gpu = np.abs(N_(out.u)[:, over_bar] - u_ld).max(axis=0)
@@ -688,7 +697,8 @@ def test_long_horizon_fp32_stays_finite(pkg):
     x0[1] = np.pi / 2 + rng.uniform(-0.05, 0.05, 64)
     over = dict(window_length=160, state_spacing=10, max_iterations=2, u_cost_weight=0.0)
     for pipe in ("fused", "split"):
-        opt = pkg.BatchOptimization(pkg.default_params(**over), max_batch=64, dtype=torch.float32, device=0)
+        opt = pkg.BatchOptimization(pkg.default_params(**over), max_batch=64, dtype=torch.float32, device=0,
+                                    allow_long_horizon=True)
         opt.set_pipeline(pipe)
         out = opt.step(T(x0, torch.float32), DYN_UI, 0.0)
         assert torch.isfinite(out.u).all() and torch.isfinite(out.predicted_states).all()

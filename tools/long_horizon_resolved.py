@@ -14,7 +14,7 @@ u_cpu, _, st_cpu, it_cpu, _ = orc.step_batch_cold(orc.default_opt_params(**over)
 for pipe in ("fused", "split"):
     for its in (1, 2, 3):
         ov = dict(over, max_iterations=its)
-        opt = pkg.BatchOptimization(pkg.default_params(**ov), max_batch=B, dtype=torch.float64, device=0); opt.set_pipeline(pipe)
+        opt = pkg.BatchOptimization(pkg.default_params(**ov), max_batch=B, dtype=torch.float64, device=0, allow_long_horizon=True); opt.set_pipeline(pipe)
         u = opt.step(torch.tensor(x, dtype=torch.float64, device="cuda:0"), DYN_UI, 0.0).u.cpu().numpy()
         uc = u_cpu if its == 3 else orc.step_batch_cold(orc.default_opt_params(**ov), DYN_UI, 0.0, x, num_threads=16)[0]
         e = np.abs(u - uc).max(axis=0)

@@ -48,6 +48,10 @@ CASES = [
     ("run to the fixed point: 200 its, exits off (the full-step rule at scale)", 32768, dict(NO_TOL, max_iterations=200), DYN_UI, 0.0, "single", "auto"),
     ("the same, split pipeline", 16384, dict(NO_TOL, max_iterations=200), DYN_UI, 0.0, "single", "split"),
     ("N=80 sp=10 (8 intervals), 4 its", 32768, dict(NO_TOL, window_length=80, max_iterations=4), DYN_UI, 0.0, "single", "auto"),
+    # where does the condensed QP stop reproducing the full-space solve?  (cpmpc_max_parity_horizon: the library refuses
+    # horizons beyond 0.8 s unless CPMPC_CREATE_ALLOW_LONG_HORIZON is given)
+    ("N=100 sp=10 (10 intervals), 3 its", 16384, dict(NO_TOL, window_length=100, max_iterations=3), DYN_UI, 0.0, "single", "auto"),
+    ("N=120 sp=12 (10 intervals), 3 its", 16384, dict(NO_TOL, window_length=120, state_spacing=12, max_iterations=3), DYN_UI, 0.0, "single", "auto"),
     ("N=160 sp=10 (16 intervals), 3 its", 16384, dict(NO_TOL, window_length=160, max_iterations=3), DYN_UI, 0.0, "single", "auto"),
 ]
 
@@ -58,7 +62,8 @@ def main():
     for i, (tag, B, over, dyn, sp, model, pipe) in enumerate(CASES):
         rng = np.random.default_rng(500 + i)
         x0 = states(rng, B, model)
-        opt = pkg.BatchOptimization(pkg.default_params(**over), max_batch=B, dtype=torch.float64, device=0, model=model)
+        opt = pkg.BatchOptimization(pkg.default_params(**over), max_batch=B, dtype=torch.float64, device=0, model=model,
+                                    allow_long_horizon=True)
         opt.set_pipeline(pipe)
         t0 = time.perf_counter()
         out = opt.step(torch.tensor(x0, dtype=torch.float64, device="cuda:0"), dyn, sp, want_stats=True)
