@@ -599,9 +599,29 @@ extern "C" int cpmpc_host_unregister(void* ptr) {
 
 extern "C" int cpmpc_set_host_chunk(cpmpc_solver* s, int64_t problems) {
   if (!s) return fail(CPMPC_ERR_INVALID_ARG, "null solver");
-  if (problems < 0) return fail(CPMPC_ERR_INVALID_ARG, "chunk size must be >= 0 (0 = never split)");
-  s->host_chunk = problems == 0 ? 0 : (problems + 63) / 64 * 64;
+  if (problems < -1) return fail(CPMPC_ERR_INVALID_ARG, "chunk size must be >= 0 (0 = never split), or -1 for the default");
+  s->host_chunk = problems <= 0 ? problems : (problems + 63) / 64 * 64;
   return CPMPC_OK;
+}
+
+static bool host_ptr_is_pinned(const void* p) {
+  if (!p) return false;
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError();  // an ordinary (pageable) host pointer is reported as an error
+    return false;
+  }
+  return at.type == hipMemoryTypeHost;
+}
+
+// DMA straight into the caller's arrays pays when the predicted states are asked for (160 of the 200 rows a problem
+// returns) and every real-typed output array is pinned; for u alone the worker threads' scatter of the mirror is hidden
+// behind the kernels and the strided device-to-host copies are not (measured, profiles/r04_host_path.json).
+static bool host_direct_outputs(const cpmpc_solver* s, const cpmpc_step_host_outputs& out) {
+  if (s->dtype != CPMPC_F64 || out.predicted == nullptr) return false;
+  if (!host_ptr_is_pinned(out.predicted) || !host_ptr_is_pinned(out.u)) return false;
+  if (out.solution && !host_ptr_is_pinned(out.solution)) return false;
+  return true;
 }
 
 // One chunk of a host-pointer step: problems [c0, c0 + Bc) of handle h = columns [g0, g0 + Bc) of the caller's arrays
@@ -611,10 +631,15 @@ struct HostWork {
 };
 
 // the chunks of problems [0, Bh) of handle h (its columns start at g_base in the caller's arrays), appended to `work`
-static void host_chunks_of(cpmpc_solver* h, int64_t Bh, int64_t g_base, std::vector<std::vector<HostWork>>& per_handle) {
+static void host_chunks_of(cpmpc_solver* h, int64_t Bh, int64_t g_base, bool direct,
+                           std::vector<std::vector<HostWork>>& per_handle) {
   std::vector<HostWork> w;
   int64_t n = 1;
-  if (h->host_chunk > 0 && Bh > h->host_chunk + h->host_chunk / 2) n = (Bh + h->host_chunk - 1) / h->host_chunk;
+  // default: eight chunks of at least 16 384 problems; sixteen of at least 8 192 when the results travel by DMA into the
+  // caller's arrays (no CPU scatter to amortise: smaller chunks shorten the drain of the pipeline)
+  int64_t chunk = h->host_chunk;
+  if (chunk < 0) chunk = direct ? (Bh / 16 > 8192 ? Bh / 16 : 8192) : (Bh / 8 > 16384 ? Bh / 8 : 16384);
+  if (chunk > 0 && Bh > chunk + chunk / 2) n = (Bh + chunk - 1) / chunk;
   const int64_t step = ((Bh + n - 1) / n + 63) / 64 * 64;
   for (int64_t c0 = 0; c0 < Bh; c0 += step) w.push_back(HostWork{h, c0, (Bh - c0 < step ? Bh - c0 : step), g_base + c0});
   per_handle.push_back(std::move(w));
@@ -625,7 +650,7 @@ static void host_chunks_of(cpmpc_solver* h, int64_t Bh, int64_t g_base, std::vec
 // handles (the shards of cpmpc_sharded_*) are issued round-robin.  Results do not depend on the chunking: a problem's
 // arithmetic does not depend on the lanes it occupies or on its neighbours.  Returns after every chunk has landed.
 static int run_host_pipeline(const std::vector<std::vector<HostWork>>& per_handle, int64_t ld,
-                             const cpmpc_step_host_inputs& in, const cpmpc_step_host_outputs& out) {
+                             const cpmpc_step_host_inputs& in, const cpmpc_step_host_outputs& out, bool direct) {
   struct Flight {
     cpmpc_solver* h;
     int slot;
@@ -654,7 +679,7 @@ static int run_host_pipeline(const std::vector<std::vector<HostWork>>& per_handl
       while (c.h->slot[slot].busy && !inflight.empty()) end_front();  // oldest first: it is the one most likely done
       if (first_rc != CPMPC_OK) break;
       DeviceGuard guard(c.h->device);
-      const int rc = engine_of(c.h)->host_chunk_begin(c.h, slot, c.c0, c.Bc, c.g0, ld, in, out);
+      const int rc = engine_of(c.h)->host_chunk_begin(c.h, slot, c.c0, c.Bc, c.g0, ld, in, out, direct);
       if (rc != CPMPC_OK) {
         first_rc = rc;
         break;
@@ -684,8 +709,10 @@ extern "C" int cpmpc_step_batch_host_in(cpmpc_solver* s, int64_t B, const cpmpc_
   if (B < 1) return fail(CPMPC_ERR_INVALID_ARG, "B must be >= 1");
   if (B > s->cap) return fail(CPMPC_ERR_BATCH, "B exceeds capacity");
   std::vector<std::vector<HostWork>> work;
-  host_chunks_of(s, B, 0, work);
-  return run_host_pipeline(work, B, *in, *out);
+  DeviceGuard guard(s->device);
+  const bool direct = host_direct_outputs(s, *out);
+  host_chunks_of(s, B, 0, direct, work);
+  return run_host_pipeline(work, B, *in, *out, direct);
 }
 
 extern "C" int cpmpc_step_batch_host_ex(cpmpc_solver* s, int64_t B, const double* x0_host,
@@ -1038,12 +1065,17 @@ extern "C" int cpmpc_sharded_step_batch_host_in(cpmpc_sharded* s, int64_t B, con
   const int n = (int)s->shards.size();
   // every shard's chunks -- upload, kernels, download on its own streams -- are in flight together
   std::vector<std::vector<HostWork>> work;
+  bool direct;
+  {
+    DeviceGuard guard(s->shards[0].device);
+    direct = host_direct_outputs(s->shards[0].h, *out);
+  }
   for (int i = 0; i < n; ++i) {
     int64_t lo, hi;
     shard_range(B, i, n, &lo, &hi);
-    if (hi > lo) host_chunks_of(s->shards[i].h, hi - lo, lo, work);
+    if (hi > lo) host_chunks_of(s->shards[i].h, hi - lo, lo, direct, work);
   }
-  rc = run_host_pipeline(work, B, *in, *out);
+  rc = run_host_pipeline(work, B, *in, *out, direct);
   if (rc == CPMPC_OK) s->warm_total = B;
   else cpmpc_sharded_reset(s);  // some shards stepped, others did not: no consistent warm start is left
   return rc;

@@ -68,7 +68,7 @@ struct cpmpc_solver {
   int64_t prev_B = 0;  // problems [0, prev_B) hold a previous solution; Reset() -> 0
   // staging for the *_host entry points (lazily allocated, grown on demand, owned by the handle)
   HostSlot slot[kHostSlots];
-  int64_t host_chunk = 32768;    // problems per chunk of a pipelined host-pointer step (cpmpc_set_host_chunk)
+  int64_t host_chunk = -1;       // problems per chunk of a pipelined host-pointer step (cpmpc_set_host_chunk); -1 = by batch size
   hipEvent_t ev_last = nullptr;  // end of the last device-pointer call on a caller's stream; the slot streams wait on it
   bool ev_pending = false;
   // profiling
@@ -128,8 +128,9 @@ struct Engine {
   // one chunk of a host-pointer step in two halves: `begin` converts and uploads problems [c0, c0 + Bc) of the handle
   // (columns [g0, g0 + Bc) of the caller's [field][ld] arrays), queues the kernels and the copy back on the slot's
   // stream; `end` waits for it and scatters the results into the caller's arrays
+  // (direct: copy the real-typed outputs by DMA straight into the caller's pinned arrays -- decided once per call)
   int (*host_chunk_begin)(cpmpc_solver* s, int slot, int64_t c0, int64_t Bc, int64_t g0, int64_t ld,
-                          const cpmpc_step_host_inputs& in, const cpmpc_step_host_outputs& out);
+                          const cpmpc_step_host_inputs& in, const cpmpc_step_host_outputs& out, bool direct);
   int (*host_chunk_end)(cpmpc_solver* s, int slot, int64_t ld, const cpmpc_step_host_outputs& out);
   // packed z [dim][B] (MapKey order) <-> workspace
   void (*pack_z)(cpmpc_solver* s, int64_t B, const void* z, hipStream_t stream);

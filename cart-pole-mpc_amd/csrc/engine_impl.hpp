@@ -313,19 +313,9 @@ struct RowCopy {
   }
 };
 
-static bool host_ptr_is_pinned(const void* p) {
-  if (!p) return false;
-  hipPointerAttribute_t at;
-  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
-    (void)hipGetLastError();  // an ordinary (pageable) host pointer is reported as an error
-    return false;
-  }
-  return at.type == hipMemoryTypeHost;
-}
-
 template <typename R, typename M>
 static int host_chunk_begin(cpmpc_solver* s, int slot_i, int64_t c0, int64_t Bc, int64_t g0, int64_t ld,
-                            const cpmpc_step_host_inputs& in, const cpmpc_step_host_outputs& ho) {
+                            const cpmpc_step_host_inputs& in, const cpmpc_step_host_outputs& ho, bool direct) {
   const size_t nB = (size_t)Bc;
   const bool per_dyn = in.dyn != nullptr, per_sp = in.set_point != nullptr, per_tw = in.terminal_weights != nullptr;
   const bool want_pred = ho.predicted != nullptr, want_sol = ho.solution != nullptr;
@@ -377,9 +367,7 @@ static int host_chunk_begin(cpmpc_solver* s, int slot_i, int64_t c0, int64_t Bc,
   // Copy back.  A double handle whose real-typed output arrays the caller has pinned (hipHostMalloc / hipHostRegister /
   // cpmpc_host_register) gets them by DMA straight into those arrays, no pass of the CPU over the data; everything else
   // comes back into the mirror in one copy and is scattered by host_chunk_end.
-  bool direct = sizeof(R) == 8 && host_ptr_is_pinned(ho.u);
-  if (direct && want_pred && !host_ptr_is_pinned(ho.predicted)) direct = false;
-  if (direct && want_sol && !host_ptr_is_pinned(ho.solution)) direct = false;
+  direct = direct && sizeof(R) == 8;
   if (direct) {
     auto d2h = [&](double* dst, size_t off, size_t rows) -> hipError_t {
       if (!dst) return hipSuccess;

@@ -199,8 +199,12 @@ __device__ __forceinline__ R clampr(R v, R lo, R hi) {
   return v < lo ? lo : (v > hi ? hi : v);
 }
 
-// running maximum for |dz|_inf of the full-step rule: one v_max.  (The hardware maximum drops a NaN operand; a step with a
-// NaN component has made the directional quantities non-finite and terminated the problem before the rule is consulted.)
+// running maximum for |dz|_inf of the full-step rule: one v_max.  The hardware maximum DROPS a NaN operand, so a step with
+// a NaN component may still be classed "tiny" here where the CPU restatement (which propagates the NaN) says "not tiny".
+// The two then differ only in the first trial step length (1 instead of alpha_start) of a line search that cannot
+// succeed either way: every trial point has a NaN component, its merit is non-finite, and both the Armijo test and the
+// full-step rule (which demands a finite merit) reject it -- same trial count, same rejection, same damping update.  In
+// the usual case the NaN has already made g.du or |J dz|^2 non-finite and the problem is QP_INDEFINITE before this.
 template <typename R>
 __device__ __forceinline__ R nan_max(R a, R b) {
   return (sizeof(R) == 8) ? (R)__builtin_fmax((double)a, (double)b) : (R)__builtin_fmaxf((float)a, (float)b);
@@ -864,7 +868,7 @@ __global__ CPMPC_QPLS_BOUNDS void qp_ls_kernel(const SolverArgs<R, M> a) {
 
   // ---- sweep 2 (k ascending): U^T du = D^-1 y, state recovery, directional quantities -----------
   R gd = R(0), curv = R(0);
-  R dz_inf = R(0);  // |dz|_inf, for the full-step rule of the line search (a NaN component poisons it: not tiny)
+  R dz_inf = R(0);  // |dz|_inf, for the full-step rule of the line search (nan_max drops a NaN component: see above)
   {
     R dx[NX];
 #pragma unroll
@@ -959,7 +963,8 @@ __global__ CPMPC_QPLS_BOUNDS void qp_ls_kernel(const SolverArgs<R, M> a) {
   // ---- Armijo line search, lock-step over the wave ----------------------------------------------
   // Local convergence safeguard: a QP step that is tiny in every component is taken in full
   // without the merit test (the l1 merit cannot resolve the decrease such a step brings, and rejects it)
-  const bool tiny = dz_inf <= a.full_step_below;
+  // (only the undamped step: one that is small because lambda is large is no sign of convergence)
+  const bool tiny = dz_inf <= a.full_step_below && lam == R(0);
   bool active = (status == kTermNone);
   bool accepted = false;
   R alpha = tiny ? R(1) : a_start, phi_t = R(0), f_t = f, cn_t = cn;

@@ -95,8 +95,8 @@ typedef struct cpmpc_solver_opts {
   double b_x_limit;
   double u_limit;
   double ls_alpha_growth_backtracked; /* growth used instead of ls_alpha_growth when the accepted search backtracked */
-  double full_step_below; /* a QP step with |dz|_inf <= this is taken in full without the merit test (local convergence
-                           * safeguard; default 1e-4, 0 disables) */
+  double full_step_below; /* an UNDAMPED QP step (lambda = 0) with |dz|_inf <= this is taken in full without the merit
+                           * test (local convergence safeguard; default 1e-4, 0 disables) */
 } cpmpc_solver_opts;
 
 void cpmpc_default_params(cpmpc_params* p);           /* optimization.hpp:12-48 defaults */
@@ -239,16 +239,17 @@ typedef struct cpmpc_step_host_inputs {
 } cpmpc_step_host_inputs;
 int cpmpc_step_batch_host_in(cpmpc_solver* s, int64_t B, const cpmpc_step_host_inputs* in,
                              const cpmpc_step_host_outputs* out);
-/* How the host-pointer calls run (round 4).  A step of more than 1.5 x `problems` problems (default 32 768) is split into
- * chunks that rotate through three staging slots on three streams: while the CPU scatters chunk k's results into the
- * caller's arrays (on the library's worker threads; CPMPC_HOST_THREADS, default 8), chunk k+1 is copying back and chunk
- * k+2 is in the kernels.  Results are bitwise those of the unsplit call (a problem's arithmetic does not depend on its
- * neighbours).  0 = never split.  Measured at B = 262 144, fp64: see INTEGRATION.md section 4. */
+/* How the host-pointer calls run (round 4).  A step of more than 1.5 x `problems` problems is split into chunks that
+ * rotate through three staging slots on three streams: while the CPU scatters chunk k's results into the caller's arrays
+ * (on the library's worker threads; CPMPC_HOST_THREADS, default 8), chunk k+1 is copying back and chunk k+2 is in the
+ * kernels.  Results are bitwise those of the unsplit call (a problem's arithmetic does not depend on its neighbours).
+ * -1 (default): eight chunks of at least 16 384 problems (sixteen of at least 8 192 when the results go by DMA into
+ * pinned caller arrays); 0 = never split.  Measured at B = 262 144, fp64: see INTEGRATION.md section 4. */
 int cpmpc_set_host_chunk(cpmpc_solver* s, int64_t problems);
-/* Pin a host array the caller keeps (page-locks it and maps it for DMA: hipHostRegister).  When the real-typed output
- * arrays (u, predicted, solution) of a CPMPC_F64 handle's host-pointer step are pinned -- by this call, hipHostMalloc or
- * hipHostRegister -- the results are copied by DMA straight into them and no CPU pass over the data remains.  The array
- * must stay allocated until cpmpc_host_unregister. */
+/* Pin a host array the caller keeps (page-locks it and maps it for DMA: hipHostRegister).  When a CPMPC_F64 handle's
+ * host-pointer step asks for the predicted states and its real-typed output arrays (u, predicted, solution) are all
+ * pinned -- by this call, hipHostMalloc or hipHostRegister -- the results are copied by DMA straight into them and no CPU
+ * pass over the data remains.  The array must stay allocated until cpmpc_host_unregister. */
 int cpmpc_host_register(void* ptr, uint64_t bytes);
 int cpmpc_host_unregister(void* ptr);
 int cpmpc_set_previous_solution_host(cpmpc_solver* s, int64_t B, const double* z_host);

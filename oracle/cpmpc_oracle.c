@@ -895,7 +895,10 @@ static int solve(const orc_model* m, const orc_opt_params* p, const orc_solver_o
       const double aj = fabs(dz[j]);
       if (aj > dz_inf || aj != aj) dz_inf = aj; /* a NaN component makes dz_inf NaN for good: not tiny */
     }
-    const int tiny = dz_inf <= o->full_step_below; /* false for NaN and for full_step_below = 0 with any nonzero step */
+    /* Only for the UNDAMPED step (lambda = 0): a step that is small because the damping is large says nothing about the
+     * distance to the optimum, and taking it without the merit test would also lower lambda again, so that MAX_LAMBDA
+     * could no longer be reached through the controls. */
+    const int tiny = dz_inf <= o->full_step_below && lambda == 0.0; /* false for NaN and for full_step_below = 0 with any nonzero step */
     double alpha = tiny ? 1.0 : alpha_start;
     int accepted = 0, backtracked = 0;
     double phi_t = 0.0, f_t = 0.0, cn_t = 0.0;

@@ -313,6 +313,8 @@ def _random_case(rng):
         th_dot_final_cost_weight=sign(10.0 ** rng.uniform(0, 2)))
     if over["u_cost_weight"] == 0.0 and over["u_derivative_cost_weight"] == 0.0:
         over["u_cost_weight"] = 0.1                      # some control cost, or the QP is singular by construction
+    if over["window_length"] * over["control_dt"] > 0.8:
+        over["control_dt"] = 0.01                        # the library refuses horizons beyond 0.8 s unless asked (cpmpc_create_ex)
     dyn = [float(rng.uniform(0.5, 2.0)), float(rng.uniform(0.05, 0.3)), float(rng.uniform(0.15, 0.5)), 9.81,
            float(rng.choice([0.0, 0.05, 0.2])), float(rng.choice([1e-7, 0.05, 0.1])), float(rng.choice([0.0, 0.02, 0.1])),
            float(rng.uniform(0.5, 1.0)), float(rng.choice([0.0, 50.0, 100.0]))]
@@ -864,7 +866,7 @@ def test_pipeline_selection(pkg):
     for N, sp, want in ((30, 3, "fused"), (30, 6, "fused"), (30, 15, "fused"), (16, 4, "fused"), (8, 1, "fused"),
                         (21, 7, "split"), (40, 40, "split"), (400, 100, "split")):
         o = pkg.BatchOptimization(pkg.default_params(window_length=N, state_spacing=sp), max_batch=64,
-                                  dtype=torch.float32, device=0)
+                                  dtype=torch.float32, device=0, allow_long_horizon=N > 80)
         assert o.pipeline() == want, (N, sp)
     opt3 = pkg.BatchOptimization(pkg.default_params(), max_batch=64, dtype=torch.float32, device=0, model="double")
     assert opt3.pipeline() == "fused"                  # both models are built; fp64 double defaults to split (LDS)

@@ -20,6 +20,8 @@ rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR 
 # passes are optional: a counter this rocprofv3 does not know must not cost the passes above
 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 --output-format csv -d "$O/mix1" -- python3 "$R/bench.py" --steps 3 --warmup 1 "${COMMON[@]}" > "$O/mix1.log" 2>&1 || echo "mix1 pass failed (see mix1.log)"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d "$O/mix2" -- python3 "$R/bench.py" --steps 3 --warmup 1 "${COMMON[@]}" > "$O/mix2.log" 2>&1 || echo "mix2 pass failed (see mix2.log)"
+# LDS: cycles the LDS array worked for this kernel and the extra cycles bank conflicts cost
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_LDS --output-format csv -d "$O/lds" -- python3 "$R/bench.py" --steps 3 --warmup 1 "${COMMON[@]}" > "$O/lds.log" 2>&1 || echo "lds pass failed (see lds.log)"
 cd "$O"
 find . -name "*.csv" | sort | sed -n '1,30p'
 du -sh .

@@ -75,7 +75,7 @@ def main():
                     stats[k] = {"calls": int(row[1]), "avg_ns": float(row[3]), "pct": float(row[4])}
     # counters
     counters = defaultdict(dict)
-    for sub in ("fetch", "write", "sq", "sq2", "mix1", "mix2"):
+    for sub in ("fetch", "write", "sq", "sq2", "mix1", "mix2", "lds"):
         for path in newest(os.path.join(src, sub, "*", "*_counter_collection.csv")):
             for k, cs in read_counters(path).items():
                 for c, vals in cs.items():
@@ -114,6 +114,17 @@ def main():
                 "wait_any_over_wave_cycles": cs.get("SQ_WAIT_ANY", 0) / cs["SQ_WAVE_CYCLES"],
                 "valu_insts_per_wave": cs.get("SQ_INSTS_VALU", 0) / max(cs.get("SQ_WAVES", 1), 1),
             }
+    for k, cs in counters.items():   # LDS pass of prof.sh: conflict cycles against all LDS-array cycles, per wave
+        if "SQ_LDS_IDX_ACTIVE" in cs and cs.get("SQ_WAVES", 0) > 0:
+            w = cs["SQ_WAVES"]
+            summary.setdefault("lds", {})[k] = {
+                "lds_instructions_per_wave": cs.get("SQ_INSTS_LDS", 0) / w,
+                "lds_array_cycles_per_wave": cs["SQ_LDS_IDX_ACTIVE"] / w,
+                "bank_conflict_cycles_per_wave": cs.get("SQ_LDS_BANK_CONFLICT", 0) / w,
+                "addr_conflict_cycles_per_wave": cs.get("SQ_LDS_ADDR_CONFLICT", 0) / w,
+                "bank_conflict_share_of_lds_cycles": cs.get("SQ_LDS_BANK_CONFLICT", 0) / cs["SQ_LDS_IDX_ACTIVE"] if cs["SQ_LDS_IDX_ACTIVE"] else None,
+                "wait_any_over_wave_cycles": cs.get("SQ_WAIT_ANY", 0) / cs["SQ_WAVE_CYCLES"] if cs.get("SQ_WAVE_CYCLES") else None,
+                "wait_inst_lds_over_wave_cycles": cs.get("SQ_WAIT_INST_LDS", 0) / cs["SQ_WAVE_CYCLES"] if cs.get("SQ_WAVE_CYCLES") else None}
     # dynamic vector-instruction mix per wave (the mix1 / mix2 passes of prof.sh), by issue-cost class
     mix = {}
     for k, cs in counters.items():
