@@ -94,7 +94,7 @@ class BatchOptimization:
 
     def __init__(self, params, max_batch, dtype=torch.float32, device=None, opts=None, model="single",
                  allow_long_horizon=False):
-        """allow_long_horizon: accept window_length * control_dt beyond cpmpc_max_parity_horizon() (0.8 s), where the
+        """allow_long_horizon: accept window_length * control_dt beyond cpmpc_max_parity_horizon() (1.0 s), where the
         condensed QP is no longer held to 1e-5 of a full-space solve on every problem (include/cpmpc.h,
         CPMPC_CREATE_ALLOW_LONG_HORIZON); without it such parameters raise CpmpcError(ERR_UNSUPPORTED)."""
         lib = capi.load()
@@ -175,14 +175,20 @@ class BatchOptimization:
             inp.terminal_weights = None
 
         o = out if out is not None else BatchOutputs()
-        if o.u is None or tuple(o.u.shape) != (self.N, B):
+
+        def reusable(t, shape, dtype):
+            # a buffer handed back in `out` is written by the kernels as `dtype` on `dev`: anything else (another
+            # optimizer's outputs of the other precision, another device) must be replaced, never written through
+            return (t is not None and tuple(t.shape) == tuple(shape) and t.dtype == dtype and t.device == dev
+                    and t.is_contiguous())
+        if not reusable(o.u, (self.N, B), self.dtype):
             o.u = torch.empty((self.N, B), dtype=self.dtype, device=dev)
-        if want_predicted and (o.predicted_states is None
-                               or tuple(o.predicted_states.shape) != (self.N, self.nx, B)):
+        if want_predicted and not reusable(o.predicted_states, (self.N, self.nx, B), self.dtype):
             o.predicted_states = torch.empty((self.N, self.nx, B), dtype=self.dtype, device=dev)
-        if o.status is None or o.status.numel() != B:
+        if not reusable(o.status, (B,), torch.int32):
             o.status = torch.empty((B,), dtype=torch.int32, device=dev)
-        if want_stats and (o.iterations is None or o.iterations.numel() != B):
+        if want_stats and not (reusable(o.iterations, (B,), torch.int32) and reusable(o.ls_evals, (B,), torch.int32)
+                               and reusable(o.final_cost, (B,), self.dtype) and reusable(o.final_eq_l1, (B,), self.dtype)):
             o.iterations = torch.empty((B,), dtype=torch.int32, device=dev)
             o.ls_evals = torch.empty((B,), dtype=torch.int32, device=dev)
             o.final_cost = torch.empty((B,), dtype=self.dtype, device=dev)

@@ -159,7 +159,7 @@ static int validate_params(const cpmpc_params* p) {
 
 // Horizon (window_length * control_dt, seconds) up to which the condensed QP is held to 1e-5 of a full-space KKT solve on
 // every problem (include/cpmpc.h: cpmpc_max_parity_horizon)
-static const double kMaxParityHorizon = 0.8;
+static const double kMaxParityHorizon = 1.0;
 extern "C" double cpmpc_max_parity_horizon(void) { return kMaxParityHorizon; }
 
 static int create_impl(const cpmpc_params* params, const cpmpc_solver_opts* opts, size_t opts_size, int dtype,
@@ -181,7 +181,8 @@ static int create_impl(const cpmpc_params* params, const cpmpc_solver_opts* opts
       return fail(CPMPC_ERR_UNSUPPORTED,
                   "horizon window_length * control_dt = %.3f s exceeds %.1f s, the longest the condensed QP is held to 1e-5 of a "
                   "full-space solve on every problem (state elimination through an unstable plant loses ~3 digits per QP at "
-                  "1.6 s); pass CPMPC_CREATE_ALLOW_LONG_HORIZON to cpmpc_create_ex to solve it anyway", horizon, kMaxParityHorizon);
+                  "1.6 s; 2 of 16384 cold starts are beyond 1e-5 at 1.2 s); pass CPMPC_CREATE_ALLOW_LONG_HORIZON to "
+                  "cpmpc_create_ex to solve it anyway", horizon, kMaxParityHorizon);
   }
   rc = check_device(device);
   if (rc) return rc;
@@ -619,6 +620,8 @@ static bool host_ptr_is_pinned(const void* p) {
 // behind the kernels and the strided device-to-host copies are not (measured, profiles/r04_host_path.json).
 static bool host_direct_outputs(const cpmpc_solver* s, const cpmpc_step_host_outputs& out) {
   if (s->dtype != CPMPC_F64 || out.predicted == nullptr) return false;
+  if (const char* e = getenv("CPMPC_HOST_DIRECT"))  // measurement switch: 0 = always through the mirror
+    if (e[0] == '0') return false;
   if (!host_ptr_is_pinned(out.predicted) || !host_ptr_is_pinned(out.u)) return false;
   if (out.solution && !host_ptr_is_pinned(out.solution)) return false;
   return true;

@@ -11,7 +11,7 @@
 // Measured on a CPU model of the elimination (N = 40, 300 cold-start problems, error of the QP step against a long-double
 // dense KKT solve): all in float 2.7 worst / 1.0 p99 / 3e-3 median; S in double 4e-3 / 3e-3 / 1e-4 -- better than a
 // dense float KKT solve with pivoting (2e-2 / 2e-2 / 1e-3).
-// A double kernel keeps its own type.  (Round 4 tried double-double there for horizons beyond 0.8 s: it removes the
+// A double kernel keeps its own type.  (Round 4 tried double-double there for horizons beyond 1 s: it removes the
 // rounding of S but not that of W q and of the forward state recovery, which amplify by the same e^{6 t}; the result
 // was no better than plain double with its refinement pass, so it is not in the code.  Such horizons are refused at
 // creation unless asked for explicitly: include/cpmpc.h, CPMPC_CREATE_ALLOW_LONG_HORIZON.)

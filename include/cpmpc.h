@@ -124,11 +124,12 @@ void cpmpc_destroy(cpmpc_solver* s);
  *   flags      CPMPC_CREATE_ALLOW_LONG_HORIZON: accept a horizon window_length * control_dt beyond
  *              cpmpc_max_parity_horizon().  cpmpc_create / cpmpc_create_model return CPMPC_ERR_UNSUPPORTED for those:
  *              the QP is solved by eliminating the states through the shooting recursion, and through more than
- *              ~0.8 s of the default pole (unstable at e^{6.3 t}) that loses about three digits per QP against a
- *              full-space KKT solve with pivoting -- measured at window_length 160, control_dt 0.01: after three
- *              iterations from a cold start 0.5 % of the problems are beyond 1e-5 of the CPU check (worst 0.4), where
- *              window_length 80 keeps every problem within 3e-6.  With the flag such a horizon is solved as it always
- *              was; warm-started closed loops are not affected in practice, cold starts far from the optimum are.
+ *              ~1 s of the default pole (unstable at e^{6.3 t}) that loses digits against a full-space KKT solve with
+ *              pivoting -- measured at control_dt 0.01 (profiles/r04_parity_sweep.json): window_length 80 and 100 keep
+ *              every one of 32 768 cold-start problems within 3e-6 / 4e-7 of the CPU check (three to eight iterations);
+ *              at 120, 2 of 16 384 are beyond 1e-5 (worst 1.6e-5); at 160, 0.4 % are (worst 1e-2 .. 0.4 depending on
+ *              the sample).  With the flag such a horizon is solved as it always was; warm-started closed loops are
+ *              not affected in practice, cold starts far from the optimum are.
  *   opts_size  sizeof(cpmpc_solver_opts) as the CALLER was compiled (0 = this header's).  Option fields are only ever
  *              appended; a caller built against an earlier header passes its shorter size and keeps the library's
  *              defaults for the fields it does not know (full_step_below was appended in round 3).  Always start from
@@ -147,7 +148,7 @@ typedef struct cpmpc_create_info {
   uint64_t opts_size;
 } cpmpc_create_info;
 int cpmpc_create_ex(const cpmpc_create_info* info, cpmpc_solver** out);
-/* seconds: the longest horizon held to 1e-5 of the CPU check on every problem (0.8) */
+/* seconds: the longest horizon held to 1e-5 of the CPU check on every problem (1.0) */
 double cpmpc_max_parity_horizon(void);
 
 /* 2: register-resident linearisation compiled for this spacing (1,2,4,5,8,10,20); 1: served by the generic

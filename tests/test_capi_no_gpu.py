@@ -137,18 +137,18 @@ def test_fails_loudly_without_a_gpu(lib, pkg):
 
 
 def test_long_horizons_are_refused_unless_asked_for(lib, pkg):
-    """window_length * control_dt beyond cpmpc_max_parity_horizon() (0.8 s) is CPMPC_ERR_UNSUPPORTED from every positional
+    """window_length * control_dt beyond cpmpc_max_parity_horizon() (1.0 s) is CPMPC_ERR_UNSUPPORTED from every positional
     constructor, with the flag that lifts it named in the message; cpmpc_create_ex with the flag gets as far as the
     device check.  The versioned structs reject a wrong struct_size / opts_size.  (No device is needed for any of it.)"""
-    assert lib.cpmpc_max_parity_horizon() == pytest.approx(0.8)
+    assert lib.cpmpc_max_parity_horizon() == pytest.approx(1.0)
     h = C.c_void_p()
-    for over in (dict(window_length=160), dict(window_length=100), dict(control_dt=0.05)):
+    for over in (dict(window_length=160), dict(window_length=120, state_spacing=12), dict(control_dt=0.05)):
         p = pkg.capi.default_params(**over)
         assert lib.cpmpc_create(C.byref(p), None, pkg.capi.F64, 8, 0, C.byref(h)) == pkg.capi.ERR_UNSUPPORTED, over
         assert b"CPMPC_CREATE_ALLOW_LONG_HORIZON" in lib.cpmpc_last_error()
         assert lib.cpmpc_sharded_create(C.byref(p), None, pkg.capi.F64, 8, None, 0, C.byref(h)) in (
             pkg.capi.ERR_UNSUPPORTED, pkg.capi.ERR_NO_DEVICE)
-    ok = pkg.capi.default_params(window_length=80)
+    ok = pkg.capi.default_params(window_length=100)
     assert lib.cpmpc_create(C.byref(ok), None, pkg.capi.F64, 8, 0, C.byref(h)) in (pkg.capi.OK, pkg.capi.ERR_NO_DEVICE)
     if h.value:
         lib.cpmpc_destroy(h)

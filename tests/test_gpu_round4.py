@@ -127,6 +127,30 @@ def test_chunked_host_step_is_bitwise_the_unsplit_one(pkg, dtype):
         lib.cpmpc_destroy(many)
 
 
+def test_out_buffers_of_the_other_precision_are_replaced_not_written_through(pkg):
+    """BatchOptimization.step(out=...) reuses the caller's output tensors only if shape, dtype and device all match: a
+    BatchOutputs filled by an fp32 optimizer handed to an fp64 one has the right SHAPES and half the bytes (an fp64 kernel
+    writing through it runs off the end of the allocation: round 4 found this with a GPU memory fault in bench.py)."""
+    B = 4096
+    x = random_states(np.random.default_rng(2), B)
+    out = pkg.BatchOutputs()
+    o32 = pkg.BatchOptimization(pkg.default_params(**NO_TOL), max_batch=B, dtype=torch.float32, device=0)
+    o64 = pkg.BatchOptimization(pkg.default_params(**NO_TOL), max_batch=B, dtype=torch.float64, device=0)
+    o32.step(T(x, torch.float32), DYN_UI, 0.0, out=out)
+    u32 = out.u
+    assert u32.dtype == torch.float32
+    r = o64.step(T(x), DYN_UI, 0.0, out=out)
+    torch.cuda.synchronize()
+    assert r.u.dtype == torch.float64 and r.predicted_states.dtype == torch.float64 and r.final_cost.dtype == torch.float64
+    assert r.u.data_ptr() != u32.data_ptr()
+    ref = o64.step(T(x), DYN_UI, 0.0)            # warm now: compare against a fresh cold solve instead
+    o64.reset()
+    ref = o64.step(T(x), DYN_UI, 0.0)
+    assert torch.equal(ref.u, r.u)
+    again = o64.step(T(x), DYN_UI, 0.0, out=out)  # matching buffers ARE reused
+    assert again.u.data_ptr() == r.u.data_ptr()
+
+
 def test_opts_size_versions_the_solver_options(pkg):
     """cpmpc_create_ex takes sizeof(cpmpc_solver_opts) as the CALLER compiled it: a caller built against the header that
     ended before full_step_below passes that shorter size, and the library keeps its own default (1e-4) for the field

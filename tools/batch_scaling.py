@@ -1,7 +1,7 @@
 """Re-plans/s against batch size, fp32 and fp64, device-resident data (cpmpc_step_batch) and host buffers
 (cpmpc_step_batch_host through the C-ABI: one copy in, the kernels, one copy out): from which batch on the GPU path beats
 the host's cores.  Run on the GPU box from the repo root:
-    python tools/batch_scaling.py [out.json]        (default profiles/r03_batch_scaling.json)"""
+    python tools/batch_scaling.py [out.json]        (default profiles/r04_batch_scaling.json)"""
 import ctypes as C
 import importlib
 import json
@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 pkg = importlib.import_module("cart-pole-mpc_amd")
 DYN_UI = [1.0, 0.1, 0.25, 9.81, 0.05, 0.1, 0.02, 0.8, 100.0]
 OVER = dict(max_iterations=5, relative_exit_tol=0.0, absolute_first_derivative_tol=0.0)
-out_path = sys.argv[1] if len(sys.argv) > 1 else "profiles/r03_batch_scaling.json"
+out_path = sys.argv[1] if len(sys.argv) > 1 else "profiles/r04_batch_scaling.json"
 lib = pkg.capi.load()
 rows = []
 for name, dt in (("f32", torch.float32), ("f64", torch.float64)):

@@ -51,13 +51,15 @@ CASES = [
     # where does the condensed QP stop reproducing the full-space solve?  (cpmpc_max_parity_horizon: the library refuses
     # horizons beyond 0.8 s unless CPMPC_CREATE_ALLOW_LONG_HORIZON is given)
     ("N=100 sp=10 (10 intervals), 3 its", 16384, dict(NO_TOL, window_length=100, max_iterations=3), DYN_UI, 0.0, "single", "auto"),
+    ("N=100 sp=10 (10 intervals), 5 its", 32768, dict(NO_TOL, window_length=100, max_iterations=5), DYN_UI, 0.0, "single", "auto"),
+    ("N=100 sp=10, reference defaults: 8 its, exits on", 32768, dict(window_length=100), DYN_UI, 0.0, "single", "auto"),
     ("N=120 sp=12 (10 intervals), 3 its", 16384, dict(NO_TOL, window_length=120, state_spacing=12, max_iterations=3), DYN_UI, 0.0, "single", "auto"),
     ("N=160 sp=10 (16 intervals), 3 its", 16384, dict(NO_TOL, window_length=160, max_iterations=3), DYN_UI, 0.0, "single", "auto"),
 ]
 
 
 def main():
-    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03_parity_sweep.json")
+    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r04_parity_sweep.json")
     report = {"threads": THREADS, "cases": []}
     for i, (tag, B, over, dyn, sp, model, pipe) in enumerate(CASES):
         rng = np.random.default_rng(500 + i)

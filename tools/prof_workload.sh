@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: prof_workload.sh <tag> <double|closed_loop> [run_workload.py flags]   kernel trace + the SQ counters of a secondary workload
+# usage: prof_workload.sh <tag> <double|closed_loop|per_problem> [run_workload.py flags]   kernel trace + the SQ counters of a secondary workload
 set -euo pipefail
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}

@@ -3,7 +3,9 @@
   double       BASELINE configs[4]: cart + double pendulum, B = 65536, N = 40, 5 iterations, cold start
   closed_loop  the warm-started closed loop of SURVEY 8(f1): re-plan (reference defaults, exits enabled, staged fused
                pipeline with compaction) + batched Simulator step, B = 262144
-usage: run_workload.py <double|closed_loop> [--dtype f32|f64] [--steps K] [--batch B]"""
+  per_problem  BASELINE configs[2] with per-problem model parameters (+-10 %), set-points and terminal weights:
+               the SHARED = false instantiation of the fused kernel, B = 262144, 5 iterations, cold start
+usage: run_workload.py <double|closed_loop|per_problem> [--dtype f32|f64] [--steps K] [--batch B]"""
 import argparse
 import importlib
 import json
@@ -23,7 +25,7 @@ DYN_DOUBLE = [1.0, 0.1, 0.1, 0.25, 0.2, 9.81]
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("workload", choices=["double", "closed_loop"])
+    ap.add_argument("workload", choices=["double", "closed_loop", "per_problem"])
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--batch", type=int, default=0)
@@ -45,6 +47,21 @@ def main():
         def step():
             opt.reset()
             opt.step(xt, DYN_DOUBLE, 0.0, out=out)
+    elif a.workload == "per_problem":
+        B = a.batch or 262144
+        x0 = np.stack([rng.uniform(-0.6, 0.6, B), rng.uniform(-np.pi, np.pi, B), rng.uniform(-1, 1, B), rng.uniform(-3, 3, B)])
+        dyn = torch.tensor(np.array(DYN_UI)[:, None] * (1.0 + 0.1 * rng.uniform(-1, 1, (9, B))), dtype=dt, device="cuda:0")
+        sp = torch.tensor(rng.uniform(-0.2, 0.2, B), dtype=dt, device="cuda:0")
+        tw = torch.tensor(np.stack([150.0 * (1.0 + 0.2 * rng.uniform(-1, 1, B)), np.where(np.arange(B) % 3 == 0, 40.0, -1.0),
+                                    -np.ones(B), -np.ones(B)]), dtype=dt, device="cuda:0")
+        p = pkg.default_params(max_iterations=5, relative_exit_tol=0.0, absolute_first_derivative_tol=0.0)
+        opt = pkg.BatchOptimization(p, max_batch=B, dtype=dt, device=0)
+        opt.set_pipeline(a.pipeline)
+        xt = torch.tensor(x0, dtype=dt, device="cuda:0")
+
+        def step():
+            opt.reset()
+            opt.step(xt, dyn, sp, out=out, terminal_weights=tw)
     else:
         B = a.batch or 262144
         xs = np.stack([rng.uniform(-0.3, 0.3, B), np.pi / 2 + rng.uniform(-0.4, 0.4, B), rng.uniform(-0.5, 0.5, B),
