@@ -63,6 +63,12 @@ std::vector<double> ShardedOptimization::GetSolution(std::size_t B) {
 std::size_t ShardedOptimization::PreviousSolutionBatch() const noexcept {
   return static_cast<std::size_t>(cpmpc_sharded_previous_solution_batch(sharded_));
 }
+void ShardedOptimization::SetHostChunk(std::size_t problems) {
+  for (int i = 0; i < cpmpc_sharded_num_shards(sharded_); ++i) {
+    const int rc = cpmpc_set_host_chunk(cpmpc_sharded_handle(sharded_, i), static_cast<std::int64_t>(problems));
+    if (rc != CPMPC_OK) ThrowSharded(rc);
+  }
+}
 std::size_t ShardedOptimization::Dim() const noexcept {
   return static_cast<std::size_t>(cpmpc_dim(cpmpc_sharded_handle(sharded_, 0)));
 }

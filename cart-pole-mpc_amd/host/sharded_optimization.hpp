@@ -49,6 +49,8 @@ class ShardedOptimization {
   // controllers [0, n) hold a previous solution.  A step with another batch size than the last one hands the warm start
   // over to the new split first (include/cpmpc.h: "Warm starts and the batch size"); nothing is ever misaligned.
   std::size_t PreviousSolutionBatch() const noexcept;
+  // problems per chunk of every shard's host-pointer pipeline (Optimization::SetHostChunk)
+  void SetHostChunk(std::size_t problems);
   std::size_t Dim() const noexcept;
 
   std::size_t NumShards() const noexcept;

@@ -180,6 +180,7 @@ int main(int argc, char** argv) {
       c.SetHostChunk(256);  // twelve chunks through three slots
       run(c, u3, p3, s3, z3);
       ShardedOptimization b(params, B, devices);
+      b.SetHostChunk(128);  // every shard's slice in several chunks too: the shards' pipelines interleave
       run(b, u2, p2, s2, z2);
       EXPECT(same_bits(u1, u3) && same_bits(p1, p3) && same_bits(s1, s3) && same_bits(z1, z3),
              "per-problem inputs: the chunked host step differs from the unsplit one");
