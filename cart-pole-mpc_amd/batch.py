@@ -93,10 +93,12 @@ class BatchOptimization:
     """B independent pendulum::Optimization controllers solved in lock-step on one GPU."""
 
     def __init__(self, params, max_batch, dtype=torch.float32, device=None, opts=None, model="single",
-                 allow_long_horizon=False):
+                 allow_long_horizon=False, refine_qp=False):
         """allow_long_horizon: accept window_length * control_dt beyond cpmpc_max_parity_horizon() (1.0 s), where the
         condensed QP is no longer held to 1e-5 of a full-space solve on every problem (include/cpmpc.h,
-        CPMPC_CREATE_ALLOW_LONG_HORIZON); without it such parameters raise CpmpcError(ERR_UNSUPPORTED)."""
+        CPMPC_CREATE_ALLOW_LONG_HORIZON); without it such parameters raise CpmpcError(ERR_UNSUPPORTED).
+        refine_qp: the fp64 fused kernels refine the whole QP solution once (CPMPC_CREATE_REFINE_QP: 7 % slower; for
+        definitions the explicit RK4 cannot integrate stably, e.g. a friction velocity scale of 1e-7)."""
         lib = capi.load()
         self.model = capi.MODELS[model]
         self.nx = lib.cpmpc_model_state_dim(self.model)
@@ -112,7 +114,8 @@ class BatchOptimization:
         self.max_batch = int(max_batch)
         self._h = C.c_void_p()
         info = capi.CreateInfo(struct_size=C.sizeof(capi.CreateInfo),
-                               flags=capi.CREATE_ALLOW_LONG_HORIZON if allow_long_horizon else 0,
+                               flags=(capi.CREATE_ALLOW_LONG_HORIZON if allow_long_horizon else 0)
+                               | (capi.CREATE_REFINE_QP if refine_qp else 0),
                                dtype=_CAPI_DTYPE[dtype], model=self.model, device=self.device, reserved=0,
                                max_batch=self.max_batch, params=C.pointer(params),
                                opts=C.pointer(opts) if opts is not None else None,

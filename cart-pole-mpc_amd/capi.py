@@ -127,6 +127,7 @@ class StepHostOutputs(C.Structure):
 
 
 CREATE_ALLOW_LONG_HORIZON = 1
+CREATE_REFINE_QP = 2
 
 
 class CreateInfo(C.Structure):

@@ -171,7 +171,8 @@ static int create_impl(const cpmpc_params* params, const cpmpc_solver_opts* opts
   if (max_batch < 1 || max_batch > (1ll << 30)) return fail(CPMPC_ERR_INVALID_ARG, "max_batch must be in [1, 2^30]");
   int rc = validate_params(params);
   if (rc) return rc;
-  if ((flags & ~(uint32_t)CPMPC_CREATE_ALLOW_LONG_HORIZON) != 0) return fail(CPMPC_ERR_INVALID_ARG, "unknown creation flags 0x%x", flags);
+  if ((flags & ~(uint32_t)(CPMPC_CREATE_ALLOW_LONG_HORIZON | CPMPC_CREATE_REFINE_QP)) != 0)
+    return fail(CPMPC_ERR_INVALID_ARG, "unknown creation flags 0x%x", flags);
   if (opts != nullptr && (opts_size < sizeof(int32_t) || opts_size > sizeof(cpmpc_solver_opts)))
     return fail(CPMPC_ERR_INVALID_ARG, "opts_size %zu is not the size of any cpmpc_solver_opts this library knows (at most %zu)",
                 opts_size, sizeof(cpmpc_solver_opts));
@@ -196,6 +197,7 @@ static int create_impl(const cpmpc_params* params, const cpmpc_solver_opts* opts
   cpmpc_default_solver_opts(&s->opts);
   if (opts) memcpy(&s->opts, opts, opts_size);
   s->dtype = dtype;
+  s->refine_qp = (flags & CPMPC_CREATE_REFINE_QP) != 0;
   s->model = model;
   s->device = device;
   s->esize = dtype == CPMPC_F32 ? 4 : 8;

@@ -78,6 +78,7 @@ struct cpmpc_solver {
   double prof_ms[CPMPC_KERNEL_COUNT] = {0, 0, 0, 0, 0};
   int64_t prof_n[CPMPC_KERNEL_COUNT] = {0, 0, 0, 0, 0};
   int pipeline = CPMPC_PIPELINE_AUTO;
+  bool refine_qp = false;  // CPMPC_CREATE_REFINE_QP: the double fused kernels refine the whole QP solution once
   // staged fused pipeline (compaction of the still-active problems between stages); 0/0 = single launch
   int stage_first = 3, stage_next = 1;
   bool stage_auto = true;  // default: stage only batches larger than one round of resident waves

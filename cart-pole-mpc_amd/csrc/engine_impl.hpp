@@ -126,19 +126,26 @@ static void launch_linearize(const SolverArgs<R, M>& a, int SP, const XV<R, M::N
 // scalar pressure hipcc 7.2 produced wrong results for it (caught by the fp64 parity tests); there the constants
 // go through load_consts() into vector registers like per-problem parameters do.
 template <typename R, typename M>
-static void launch_fused(const SolverArgs<R, M>& a, int L, int SP, int max_iters, hipStream_t stream) {
+static void launch_fused(const SolverArgs<R, M>& a, int L, int SP, int max_iters, bool refine, hipStream_t stream) {
   {
     const int ppw = 64 / L;
     const dim3 grid((unsigned)((a.B + ppw - 1) / ppw));
+    // REFINE exists for the double kernels only (constants through vector registers there, SHARED = false)
 #define CPMPC_FUSED(LV, SPV)                                                                                \
   if (L == LV && SP == SPV) {                                                                               \
-    if constexpr (sizeof(R) == 4 || CPMPC_FUSED_SHARED_F64) {                                              \
-      if (a.dyn == nullptr) {                                                                               \
-        hipLaunchKernelGGL((fused_sqp_kernel<R, M, SPV, LV, true>), grid, dim3(64), 0, stream, a, max_iters); \
+    if constexpr (sizeof(R) == 8) {                                                                         \
+      if (refine) {                                                                                         \
+        hipLaunchKernelGGL((fused_sqp_kernel<R, M, SPV, LV, false, true>), grid, dim3(64), 0, stream, a, max_iters); \
         return;                                                                                             \
       }                                                                                                     \
     }                                                                                                       \
-    hipLaunchKernelGGL((fused_sqp_kernel<R, M, SPV, LV, false>), grid, dim3(64), 0, stream, a, max_iters);  \
+    if constexpr (sizeof(R) == 4 || CPMPC_FUSED_SHARED_F64) {                                              \
+      if (a.dyn == nullptr) {                                                                               \
+        hipLaunchKernelGGL((fused_sqp_kernel<R, M, SPV, LV, true, false>), grid, dim3(64), 0, stream, a, max_iters); \
+        return;                                                                                             \
+      }                                                                                                     \
+    }                                                                                                       \
+    hipLaunchKernelGGL((fused_sqp_kernel<R, M, SPV, LV, false, false>), grid, dim3(64), 0, stream, a, max_iters);  \
     return;                                                                                                 \
   }
     CPMPC_FUSED(4, 10)
@@ -153,13 +160,19 @@ static void launch_fused(const SolverArgs<R, M>& a, int L, int SP, int max_iters
     const size_t lds = fused_dyn_lds_bytes<R, M>(SP);
 #define CPMPC_FUSED_DYN(LV)                                                                                         \
   if (L == LV) {                                                                                                    \
-    if constexpr (sizeof(R) == 4 || CPMPC_FUSED_SHARED_F64) {                                                      \
-      if (a.dyn == nullptr) {                                                                                       \
-        hipLaunchKernelGGL((fused_sqp_dyn_kernel<R, M, LV, true>), grid, dim3(64), lds, stream, a, max_iters); \
+    if constexpr (sizeof(R) == 8) {                                                                                 \
+      if (refine) {                                                                                                 \
+        hipLaunchKernelGGL((fused_sqp_dyn_kernel<R, M, LV, false, true>), grid, dim3(64), lds, stream, a, max_iters); \
         return;                                                                                                     \
       }                                                                                                             \
     }                                                                                                               \
-    hipLaunchKernelGGL((fused_sqp_dyn_kernel<R, M, LV, false>), grid, dim3(64), lds, stream, a, max_iters);  \
+    if constexpr (sizeof(R) == 4 || CPMPC_FUSED_SHARED_F64) {                                                      \
+      if (a.dyn == nullptr) {                                                                                       \
+        hipLaunchKernelGGL((fused_sqp_dyn_kernel<R, M, LV, true, false>), grid, dim3(64), lds, stream, a, max_iters); \
+        return;                                                                                                     \
+      }                                                                                                             \
+    }                                                                                                               \
+    hipLaunchKernelGGL((fused_sqp_dyn_kernel<R, M, LV, false, false>), grid, dim3(64), lds, stream, a, max_iters);  \
     return;                                                                                                         \
   }
     CPMPC_FUSED_DYN(2)
@@ -219,7 +232,7 @@ static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* 
     a.iter_cap = total;
     a.run_out_below = (int64_t)2048 * (64 / (s->S - 1));  // problems in one round of resident waves (2 per SIMD)
     span_begin(s, CPMPC_KERNEL_FUSED, stream, &sp);
-    launch_fused<R, M>(a, s->S - 1, s->SP, staged ? s->stage_first : total, stream);
+    launch_fused<R, M>(a, s->S - 1, s->SP, staged ? s->stage_first : total, s->refine_qp, stream);
     span_end(s, stream, &sp);
     int stage = 0;
     for (int done = s->stage_first; staged && done < total; done += s->stage_next, ++stage) {
@@ -236,7 +249,7 @@ static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* 
       a.active_list = s->active + col0;
       a.active_count = count;
       const int k = (total - done < s->stage_next) ? (total - done) : s->stage_next;
-      launch_fused<R, M>(a, s->S - 1, s->SP, k, stream);
+      launch_fused<R, M>(a, s->S - 1, s->SP, k, s->refine_qp, stream);
       span_end(s, stream, &sp);  // the span is closed (its events recycled) before any early return
       if (memset_rc != hipSuccess) {
         if (col0 + B > s->prev_B) s->prev_B = col0 + B;  // prepare has already shifted the warm start: keep the handle consistent

@@ -313,7 +313,9 @@ __device__ __forceinline__ void fused_g_st(GPiece* g, int i, int lane, const XV<
 }
 
 // SHARED: the batch shares one parameter set -> the model constants stay wave-uniform (scalar registers)
-template <typename R, typename M, int SP, int L, bool SHARED>
+// REFINE (double kernels only; CPMPC_CREATE_REFINE_QP): one step of iterative refinement of the whole QP solution with
+// residuals from the original data (the block after sweep 2 in mpc_fused_body.inc)
+template <typename R, typename M, int SP, int L, bool SHARED, bool REFINE>
 __global__ CPMPC_FUSED_BOUNDS_S CPMPC_FUSED_EXTRA_ATTR void fused_sqp_kernel(const SolverArgs<R, M> a, const int max_iters) {
   constexpr int NX = M::NX;
   constexpr int PPW = 64 / L;  // problems per wave
@@ -358,7 +360,7 @@ template <typename R, typename M>
 __host__ __device__ constexpr size_t fused_dyn_lds_bytes(int sp) {
   return (size_t)sp * 64 * (4 * sizeof(R) + sizeof(XV<R, M::NX>));
 }
-template <typename R, typename M, int L, bool SHARED>
+template <typename R, typename M, int L, bool SHARED, bool REFINE>
 __global__ CPMPC_FUSED_BOUNDS void fused_sqp_dyn_kernel(const SolverArgs<R, M> a, const int max_iters) {
   constexpr int NX = M::NX;
   constexpr int PPW = 64 / L;

@@ -133,8 +133,19 @@ void cpmpc_destroy(cpmpc_solver* s);
  *   opts_size  sizeof(cpmpc_solver_opts) as the CALLER was compiled (0 = this header's).  Option fields are only ever
  *              appended; a caller built against an earlier header passes its shorter size and keeps the library's
  *              defaults for the fields it does not know (full_step_below was appended in round 3).  Always start from
- *              cpmpc_default_solver_opts: a zero-initialised struct is NOT the defaults. */
+ *              cpmpc_default_solver_opts: a zero-initialised struct is NOT the defaults.
+ *   flags      CPMPC_CREATE_REFINE_QP: the fused CPMPC_F64 kernels add one step of iterative refinement of the whole QP
+ *              solution with residuals evaluated in the original data (terminal rows through the recovered states,
+ *              stationarity through the adjoint), solved again with the factors at hand.  It brings the condensed solve
+ *              below the error of a dense KKT solve with pivoting (CPU model: worst of 150 problems 3e-14 against
+ *              3e-13 at w_u = 0, w_du = 0.1) and costs 7 % of the step (50.2 -> 46.7 M re-plans/s at B = 262 144).  Not
+ *              needed for any definition whose dynamics the explicit RK4 integrates stably: a fuzz of 200 random problem
+ *              definitions x 2 048 lanes (profiles/r04_fuzz_sweep.json) has the GPU at fault on 0 of 315 392 lanes there,
+ *              and on 18 of 94 208 lanes of the 46 definitions with v_mu_b = 1e-7 (a friction slope of 1e5..1e6 1/s that
+ *              RK4 at 10 ms cannot follow: |Phi| reaches 1e4 per interval and the terminal system's condition 1e18) --
+ *              4 with this flag.  Ignored by CPMPC_F32 handles and by the split pipeline. */
 #define CPMPC_CREATE_ALLOW_LONG_HORIZON 1u
+#define CPMPC_CREATE_REFINE_QP 2u
 typedef struct cpmpc_create_info {
   uint32_t struct_size; /* = sizeof(cpmpc_create_info) */
   uint32_t flags;

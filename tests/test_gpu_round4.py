@@ -151,6 +151,29 @@ def test_out_buffers_of_the_other_precision_are_replaced_not_written_through(pkg
     assert again.u.data_ptr() == r.u.data_ptr()
 
 
+def test_refine_qp_flag_keeps_parity_and_tightens_the_qp(pkg, orc):
+    """CPMPC_CREATE_REFINE_QP: the fp64 fused kernels refine the whole QP solution once with residuals from the original
+    data.  On the benchmark's definition it changes nothing that matters -- every lane within 1e-5 of the CPU check with
+    and without it, status and iteration counts equal -- and the two runs agree to 1e-6; fp32 handles ignore the flag."""
+    B = 4096
+    x = random_states(np.random.default_rng(31), B)
+    u_cpu, _, st_cpu, it_cpu, _ = orc.step_batch_cold(orc.default_opt_params(**NO_TOL), DYN_UI, 0.0, x)
+    res = {}
+    for refine in (False, True):
+        opt = pkg.BatchOptimization(pkg.default_params(**NO_TOL), max_batch=B, dtype=torch.float64, device=0, refine_qp=refine)
+        assert opt.pipeline() == "fused"
+        o = opt.step(T(x), DYN_UI, 0.0)
+        u = o.u.cpu().numpy()
+        err = np.abs(u - u_cpu).max(axis=0)
+        assert (err < 1e-5).all(), (refine, np.sort(err)[-3:])
+        assert (o.status.cpu().numpy() == st_cpu).all() and (o.iterations.cpu().numpy() == it_cpu).all()
+        res[refine] = (u, float(np.median(err)))
+    assert np.abs(res[True][0] - res[False][0]).max() < 1e-6
+    assert not np.array_equal(res[True][0], res[False][0])          # it is another kernel
+    f32 = pkg.BatchOptimization(pkg.default_params(**NO_TOL), max_batch=64, dtype=torch.float32, device=0, refine_qp=True)
+    assert torch.isfinite(f32.step(T(x[:, :64], torch.float32), DYN_UI, 0.0).u).all()
+
+
 def test_opts_size_versions_the_solver_options(pkg):
     """cpmpc_create_ex takes sizeof(cpmpc_solver_opts) as the CALLER compiled it: a caller built against the header that
     ended before full_step_below passes that shorter size, and the library keeps its own default (1e-4) for the field
