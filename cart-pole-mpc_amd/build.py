@@ -152,7 +152,7 @@ def build_host(force=False, verbose=False):
     for target, name in ((HOST_SMOKE, "facade_closed_loop.cc"), (SHARDED_SMOKE, "sharded_smoke.cc")):
         src = os.path.join(HERE, "..", "tests", "host", name)
         if stale(target, [src, HOST_LIB] + hdrs):
-            run([cxx] + common + ["-I" + HOST, "-o", target, src, "-L" + LIB_DIR, "-lpendulum_host", "-lcpmpc",
+            run([cxx] + common + ["-pthread", "-I" + HOST, "-o", target, src, "-L" + LIB_DIR, "-lpendulum_host", "-lcpmpc",
                                   "-Wl,-rpath,$ORIGIN"])
     try:
         import pybind11

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <random>
 #include <stdexcept>
+#include <thread>
 #include <vector>
 
 #include "optimization.hpp"
@@ -195,6 +196,39 @@ int main(int argc, char** argv) {
       EXPECT(differ > B / 2, "per-problem inputs had no effect (%zu of %zu first controls differ)", differ, B);
       std::printf("per-problem dyn / set-point / terminal rows: chunked == unsplit == %zu shards, bitwise\n", b.NumShards());
     }
+  }
+
+  // ---- two host threads, each with its own Optimization, stepping chunked batches at the same time: the library's
+  // worker pool serves one parallel copy at a time and the calls must neither deadlock nor disturb each other's results
+  {
+    const std::size_t B = 6000;
+    std::mt19937_64 rng(7);
+    std::uniform_real_distribution<double> U(-1.0, 1.0);
+    std::vector<double> xa(4 * B), xb(4 * B);
+    for (std::size_t i = 0; i < B; ++i) {
+      xa[0 * B + i] = 0.6 * U(rng); xa[1 * B + i] = M_PI * U(rng); xa[2 * B + i] = U(rng); xa[3 * B + i] = 3.0 * U(rng);
+      xb[0 * B + i] = 0.6 * U(rng); xb[1 * B + i] = M_PI * U(rng); xb[2 * B + i] = U(rng); xb[3 * B + i] = 3.0 * U(rng);
+    }
+    auto solve = [&](const std::vector<double>& x, std::vector<double>& u, std::vector<double>& pred, int reps) {
+      Optimization opt(params, B);
+      opt.SetHostChunk(512);
+      u.assign(N * B, 0.0);
+      pred.assign(4 * N * B, 0.0);
+      for (int r = 0; r < reps; ++r) {
+        opt.Reset();
+        opt.StepBatchInto(x.data(), B, dyn, 0.01, PerProblemInputs{}, u.data(), pred.data(), nullptr, nullptr, nullptr, nullptr, nullptr);
+      }
+    };
+    std::vector<double> ua, pa, ub, pb, ua2, pa2, ub2, pb2;
+    solve(xa, ua, pa, 1);
+    solve(xb, ub, pb, 1);
+    std::thread ta([&] { solve(xa, ua2, pa2, 6); });
+    std::thread tb([&] { solve(xb, ub2, pb2, 6); });
+    ta.join();
+    tb.join();
+    EXPECT(same_bits(ua, ua2) && same_bits(pa, pa2) && same_bits(ub, ub2) && same_bits(pb, pb2),
+           "two threads stepping chunked batches concurrently changed a result");
+    std::printf("two host threads x 6 chunked steps of %zu controllers: bitwise the serial results\n", B);
   }
 
   // capacity and argument errors surface as exceptions, like Optimization's

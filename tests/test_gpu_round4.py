@@ -324,6 +324,7 @@ def test_sharded_cpp_facade_hand_over_and_per_problem_inputs():
     r = subprocess.run([os.path.join(LIB_DIR, "sharded_smoke"), "0", "0", "0"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "OK sharded" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
     assert "warm-start hand-over across batch sizes" in r.stdout and "chunked == unsplit == 3 shards" in r.stdout
+    assert "two host threads x 6 chunked steps" in r.stdout   # the worker pool under two concurrent callers
 
 
 def test_bench_with_four_ranks_on_the_one_gpu():

@@ -23,6 +23,7 @@ ap.add_argument("--batch", type=int, default=262144)
 ap.add_argument("--ticks", type=int, default=1000)
 ap.add_argument("--start", choices=["near-upright", "anywhere"], default="anywhere")
 ap.add_argument("--fo-tol", type=float, default=None, help="absolute_first_derivative_tol (reference default 1e-6)")
+ap.add_argument("--pipeline", choices=["auto", "split", "fused"], default="auto")
 ap.add_argument("--out", default=None)
 args = ap.parse_args()
 dt = torch.float32 if args.dtype == "f32" else torch.float64
@@ -36,6 +37,7 @@ sim = pkg.BatchSimulator(B, dtype=dt, device=0)
 sim.set_state(torch.tensor(x0, dtype=dt, device="cuda:0"))
 over = {} if args.fo_tol is None else {"absolute_first_derivative_tol": args.fo_tol}
 opt = pkg.BatchOptimization(pkg.default_params(**over), max_batch=B, dtype=dt, device=0)
+opt.set_pipeline(args.pipeline)
 out = pkg.BatchOutputs()
 names = pkg.capi.TERM_NAMES
 hist_total = {}
@@ -61,7 +63,7 @@ torch.cuda.synchronize()
 wall = time.perf_counter() - t0
 s = sim.get_state().double().cpu().numpy()
 err = np.abs(s[1] - np.pi / 2)
-res = {"dtype": args.dtype, "absolute_first_derivative_tol": args.fo_tol if args.fo_tol is not None else 1e-6, "batch": B, "ticks": args.ticks, "start": args.start, "wall_s": wall, "ms_per_tick": wall / args.ticks * 1e3,
+res = {"dtype": args.dtype, "pipeline": opt.pipeline(), "absolute_first_derivative_tol": args.fo_tol if args.fo_tol is not None else 1e-6, "batch": B, "ticks": args.ticks, "start": args.start, "wall_s": wall, "ms_per_tick": wall / args.ticks * 1e3,
        "controller_ticks_per_s": B * args.ticks / wall, "status_histogram_total": hist_total,
        "ticks_with_QP_INDEFINITE_MAX_LAMBDA_or_NON_FINITE": len(bad_ticks), "first_such_ticks": bad_ticks[:20],
        "final": {"upright_within_1e-3": float((err < 1e-3).mean()), "upright_within_1e-4": float((err < 1e-4).mean()),
