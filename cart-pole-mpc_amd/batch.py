@@ -93,12 +93,12 @@ class BatchOptimization:
     """B independent pendulum::Optimization controllers solved in lock-step on one GPU."""
 
     def __init__(self, params, max_batch, dtype=torch.float32, device=None, opts=None, model="single",
-                 allow_long_horizon=False, refine_qp=False):
+                 allow_long_horizon=False, refine_qp=None):
         """allow_long_horizon: accept window_length * control_dt beyond cpmpc_max_parity_horizon() (1.0 s), where the
         condensed QP is no longer held to 1e-5 of a full-space solve on every problem (include/cpmpc.h,
         CPMPC_CREATE_ALLOW_LONG_HORIZON); without it such parameters raise CpmpcError(ERR_UNSUPPORTED).
-        refine_qp: the fp64 fused kernels refine the whole QP solution once (CPMPC_CREATE_REFINE_QP: 7 % slower; for
-        definitions the explicit RK4 cannot integrate stably, e.g. a friction velocity scale of 1e-7)."""
+        refine_qp: True / False force on / off the refinement of the whole QP solution in the fp64 fused kernels
+        (CPMPC_CREATE_[NO_]REFINE_QP: 7 % slower); None = the library's default: on when u_cost_weight < 0.05."""
         lib = capi.load()
         self.model = capi.MODELS[model]
         self.nx = lib.cpmpc_model_state_dim(self.model)
@@ -115,7 +115,7 @@ class BatchOptimization:
         self._h = C.c_void_p()
         info = capi.CreateInfo(struct_size=C.sizeof(capi.CreateInfo),
                                flags=(capi.CREATE_ALLOW_LONG_HORIZON if allow_long_horizon else 0)
-                               | (capi.CREATE_REFINE_QP if refine_qp else 0),
+                               | (0 if refine_qp is None else (capi.CREATE_REFINE_QP if refine_qp else capi.CREATE_NO_REFINE_QP)),
                                dtype=_CAPI_DTYPE[dtype], model=self.model, device=self.device, reserved=0,
                                max_batch=self.max_batch, params=C.pointer(params),
                                opts=C.pointer(opts) if opts is not None else None,
@@ -259,6 +259,10 @@ class BatchOptimization:
     def set_pipeline(self, mode):
         """'auto' | 'split' | 'fused' (include/cpmpc.h: CPMPC_PIPELINE_*)."""
         capi.check(capi.load().cpmpc_set_pipeline(self._h, capi.PIPELINES[mode]))
+
+    @property
+    def refines_qp(self):
+        return bool(capi.load().cpmpc_refines_qp(self._h))
 
     def set_compaction(self, first_iterations=3, next_iterations=1):
         """Staging of the fused pipeline when exit tolerances are enabled (0, 0 = one launch).  Speed only."""

@@ -160,6 +160,8 @@ static int validate_params(const cpmpc_params* p) {
 // Horizon (window_length * control_dt, seconds) up to which the condensed QP is held to 1e-5 of a full-space KKT solve on
 // every problem (include/cpmpc.h: cpmpc_max_parity_horizon)
 static const double kMaxParityHorizon = 1.0;
+// u_cost_weight below which the fp64 fused kernels refine the whole QP solution by default (half the reference's 0.1)
+static const double kRefineBelowUCostWeight = 0.05;
 extern "C" double cpmpc_max_parity_horizon(void) { return kMaxParityHorizon; }
 
 static int create_impl(const cpmpc_params* params, const cpmpc_solver_opts* opts, size_t opts_size, int dtype,
@@ -171,8 +173,10 @@ static int create_impl(const cpmpc_params* params, const cpmpc_solver_opts* opts
   if (max_batch < 1 || max_batch > (1ll << 30)) return fail(CPMPC_ERR_INVALID_ARG, "max_batch must be in [1, 2^30]");
   int rc = validate_params(params);
   if (rc) return rc;
-  if ((flags & ~(uint32_t)(CPMPC_CREATE_ALLOW_LONG_HORIZON | CPMPC_CREATE_REFINE_QP)) != 0)
+  if ((flags & ~(uint32_t)(CPMPC_CREATE_ALLOW_LONG_HORIZON | CPMPC_CREATE_REFINE_QP | CPMPC_CREATE_NO_REFINE_QP)) != 0)
     return fail(CPMPC_ERR_INVALID_ARG, "unknown creation flags 0x%x", flags);
+  if ((flags & CPMPC_CREATE_REFINE_QP) && (flags & CPMPC_CREATE_NO_REFINE_QP))
+    return fail(CPMPC_ERR_INVALID_ARG, "CPMPC_CREATE_REFINE_QP and CPMPC_CREATE_NO_REFINE_QP exclude each other");
   if (opts != nullptr && (opts_size < sizeof(int32_t) || opts_size > sizeof(cpmpc_solver_opts)))
     return fail(CPMPC_ERR_INVALID_ARG, "opts_size %zu is not the size of any cpmpc_solver_opts this library knows (at most %zu)",
                 opts_size, sizeof(cpmpc_solver_opts));
@@ -197,7 +201,9 @@ static int create_impl(const cpmpc_params* params, const cpmpc_solver_opts* opts
   cpmpc_default_solver_opts(&s->opts);
   if (opts) memcpy(&s->opts, opts, opts_size);
   s->dtype = dtype;
-  s->refine_qp = (flags & CPMPC_CREATE_REFINE_QP) != 0;
+  // default: refine where the control cost is weak (measured: include/cpmpc.h, CPMPC_CREATE_REFINE_QP)
+  s->refine_qp = (flags & CPMPC_CREATE_REFINE_QP) != 0 ||
+                 (!(flags & CPMPC_CREATE_NO_REFINE_QP) && params->u_cost_weight < kRefineBelowUCostWeight);
   s->model = model;
   s->device = device;
   s->esize = dtype == CPMPC_F32 ? 4 : 8;
@@ -323,6 +329,7 @@ extern "C" int cpmpc_dim(const cpmpc_solver* s) { return s ? s->dim : -1; }
 extern "C" int cpmpc_num_states(const cpmpc_solver* s) { return s ? s->S : -1; }
 extern "C" int cpmpc_dtype(const cpmpc_solver* s) { return s ? s->dtype : -1; }
 extern "C" int cpmpc_model(const cpmpc_solver* s) { return s ? s->model : -1; }
+extern "C" int cpmpc_refines_qp(const cpmpc_solver* s) { return s ? (s->refine_qp && s->dtype == CPMPC_F64 ? 1 : 0) : -1; }
 extern "C" int cpmpc_has_previous_solution(const cpmpc_solver* s) { return (s && s->prev_B > 0) ? 1 : 0; }
 extern "C" int64_t cpmpc_previous_solution_batch(const cpmpc_solver* s) { return s ? s->prev_B : 0; }
 

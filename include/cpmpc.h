@@ -134,18 +134,25 @@ void cpmpc_destroy(cpmpc_solver* s);
  *              appended; a caller built against an earlier header passes its shorter size and keeps the library's
  *              defaults for the fields it does not know (full_step_below was appended in round 3).  Always start from
  *              cpmpc_default_solver_opts: a zero-initialised struct is NOT the defaults.
- *   flags      CPMPC_CREATE_REFINE_QP: the fused CPMPC_F64 kernels add one step of iterative refinement of the whole QP
- *              solution with residuals evaluated in the original data (terminal rows through the recovered states,
- *              stationarity through the adjoint), solved again with the factors at hand.  It brings the condensed solve
- *              below the error of a dense KKT solve with pivoting (CPU model: worst of 150 problems 3e-14 against
- *              3e-13 at w_u = 0, w_du = 0.1) and costs 7 % of the step (50.2 -> 46.7 M re-plans/s at B = 262 144).  Not
- *              needed for any definition whose dynamics the explicit RK4 integrates stably: a fuzz of 200 random problem
- *              definitions x 2 048 lanes (profiles/r04_fuzz_sweep.json) has the GPU at fault on 0 of 315 392 lanes there,
- *              and on 18 of 94 208 lanes of the 46 definitions with v_mu_b = 1e-7 (a friction slope of 1e5..1e6 1/s that
- *              RK4 at 10 ms cannot follow: |Phi| reaches 1e4 per interval and the terminal system's condition 1e18) --
- *              4 with this flag.  Ignored by CPMPC_F32 handles and by the split pipeline. */
+ *   flags      CPMPC_CREATE_REFINE_QP / CPMPC_CREATE_NO_REFINE_QP: force on / off one step of iterative refinement of the
+ *              whole QP solution in the fused CPMPC_F64 kernels -- residuals evaluated in the original data (terminal rows
+ *              through the recovered states, stationarity through the adjoint), solved again with the factors at hand.
+ *              It brings the condensed solve below the error of a dense KKT solve with pivoting (CPU model, worst of
+ *              150 problems: 3e-14 against 3e-13 at w_u = 0, w_du = 0.1) and costs 7 % of the step (50.2 -> 46.7 M
+ *              re-plans/s at B = 262 144).  DEFAULT (neither flag): on when u_cost_weight < 0.05, half the reference's
+ *              0.1.  Measured (profiles/r04_fuzz_sweep_2000*.json: 2 000 random problem definitions x 2 048 lanes, the
+ *              extended-precision arbiter on every lane that is off; "at fault" = beyond 1e-5 and more than twice as far
+ *              from the extended-precision answer as the double CPU check):
+ *                 u_cost_weight >= 0.05:  0 of 1 798 144 lanes at fault, refined or not;
+ *                 u_cost_weight <  0.05:  144 of 1 374 208 without the refinement, 16 with it (7 of those in the split
+ *                                         pipeline, which does not have it; the rest are runs into the +-300 N clamp);
+ *                 and, whatever the weights, definitions whose friction the explicit RK4 cannot follow (v_mu_b = 1e-7
+ *                 with mu_b > 0: a slope of 1e5..1e6 1/s against a stability limit of 280 1/s at 10 ms; |Phi| reaches
+ *                 1e4 per interval, the terminal system's condition 1e18): 281 of 923 648 lanes, 72 with it.
+ *              Ignored by CPMPC_F32 handles and by the split pipeline; cpmpc_refines_qp() tells what a handle does. */
 #define CPMPC_CREATE_ALLOW_LONG_HORIZON 1u
 #define CPMPC_CREATE_REFINE_QP 2u
+#define CPMPC_CREATE_NO_REFINE_QP 4u
 typedef struct cpmpc_create_info {
   uint32_t struct_size; /* = sizeof(cpmpc_create_info) */
   uint32_t flags;
@@ -159,6 +166,7 @@ typedef struct cpmpc_create_info {
   uint64_t opts_size;
 } cpmpc_create_info;
 int cpmpc_create_ex(const cpmpc_create_info* info, cpmpc_solver** out);
+int cpmpc_refines_qp(const cpmpc_solver* s); /* 1: this handle's kernels refine the QP solution (CPMPC_CREATE_REFINE_QP) */
 /* seconds: the longest horizon held to 1e-5 of the CPU check on every problem (1.0) */
 double cpmpc_max_parity_horizon(void);
 

@@ -172,6 +172,12 @@ def test_refine_qp_flag_keeps_parity_and_tightens_the_qp(pkg, orc):
     assert not np.array_equal(res[True][0], res[False][0])          # it is another kernel
     f32 = pkg.BatchOptimization(pkg.default_params(**NO_TOL), max_batch=64, dtype=torch.float32, device=0, refine_qp=True)
     assert torch.isfinite(f32.step(T(x[:, :64], torch.float32), DYN_UI, 0.0).u).all()
+    assert not f32.refines_qp
+    # the default: on where the control cost is weak (u_cost_weight < 0.05), off at the reference's 0.1
+    mk = lambda **kw: pkg.BatchOptimization(pkg.default_params(**dict(NO_TOL, **kw)), max_batch=64, dtype=torch.float64, device=0)  # noqa: E731
+    assert not mk().refines_qp and mk(u_cost_weight=0.01).refines_qp and mk(u_cost_weight=0.0).refines_qp
+    assert not pkg.BatchOptimization(pkg.default_params(**dict(NO_TOL, u_cost_weight=0.0)), max_batch=64, dtype=torch.float64,
+                                     device=0, refine_qp=False).refines_qp
 
 
 def test_opts_size_versions_the_solver_options(pkg):

@@ -25,7 +25,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("out", nargs="?", default=os.path.join(ROOT, "profiles", "r04_fuzz_sweep.json"))
 ap.add_argument("--seeds", type=int, default=200)
 ap.add_argument("--lanes", type=int, default=2048)
-ap.add_argument("--refine-qp", action="store_true", help="create the handles with CPMPC_CREATE_REFINE_QP")
+ap.add_argument("--refine-qp", choices=["auto", "on", "off"], default="auto",
+                help="CPMPC_CREATE_REFINE_QP / NO_REFINE_QP / the library's default (on when u_cost_weight < 0.05)")
 ap.add_argument("--per-problem-lanes", type=int, default=256, help="lanes of each case also solved with per-problem inputs")
 args = ap.parse_args()
 THREADS = int(os.environ.get("CPMPC_ORACLE_THREADS", "16"))
@@ -49,7 +50,8 @@ for seed in range(args.seeds):
     over, dyn, sp = random_case(rng)
     B = args.lanes
     x0 = states(rng, B)
-    opt = pkg.BatchOptimization(pkg.default_params(**over), max_batch=B, dtype=torch.float64, device=0, refine_qp=args.refine_qp)
+    opt = pkg.BatchOptimization(pkg.default_params(**over), max_batch=B, dtype=torch.float64, device=0,
+                                refine_qp={"auto": None, "on": True, "off": False}[args.refine_qp])
     out = opt.step(torch.tensor(x0, dtype=torch.float64, device="cuda:0"), dyn, sp, want_stats=True)
     u_g, st_g, it_g = out.u.cpu().numpy(), out.status.cpu().numpy(), out.iterations.cpu().numpy()
     u_c, _, st_c, it_c, _ = orc.step_batch_cold(orc.default_opt_params(**over), dyn, sp, x0, num_threads=THREADS)
