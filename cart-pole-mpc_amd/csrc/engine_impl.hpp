@@ -76,6 +76,7 @@ static void fill_args(const cpmpc_solver* s, int64_t B, SolverArgs<R, M>& a, int
   // problems [col0, col0 + B) of the workspace: every field is [field][cap] with the problem index fastest, so the call
   // works on a column range by offsetting the field bases (a chunk of a pipelined host-pointer step)
   a.prev_B = s->prev_B - col0 < 0 ? 0 : (s->prev_B - col0 > B ? B : s->prev_B - col0);
+  a.refine_qp = s->refine_qp ? 1 : 0;
   using V4 = typename VecT<R>::V4;
   using XVn = XV<R, M::NX>;
   a.zx = (XVn*)s->zx + col0;

@@ -127,6 +127,7 @@ struct SolverArgs {
   R bx_lim, u_lim;
   R rel_tol, fo_tol, mu_init;
   int64_t prev_B;  // problems [0, prev_B) hold a previous solution (warm start); the others start cold
+  int refine_qp;   // split pipeline, double: refine the whole QP solution once (the fused kernels select it by template)
   // workspace (device)
   XVn* zx;   // [S]        shooting nodes of the iterate          } persist between calls:
   R* zu;     // [N]        controls of the iterate                } the warm start
@@ -788,8 +789,8 @@ __global__ CPMPC_QPLS_BOUNDS void qp_ls_kernel(const SolverArgs<R, M> a) {
 
   // ---- (S + Dg) q = h - rho by LDL^T on the lower triangle, in registers ------------------------
   R q[NX];
+  W Lm[NX][NX], dv[NX], idv[NX];  // (function scope: the refinement after sweep 2 solves with them again)
   {
-    W Lm[NX][NX], dv[NX], idv[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) Sm[i][i] += WO::of(Dg[i]);
 #pragma unroll
@@ -933,6 +934,153 @@ __global__ CPMPC_QPLS_BOUNDS void qp_ls_kernel(const SolverArgs<R, M> a) {
         const R jd = Rw[t] * dx[t];
         gd += (Rw[t] * e_term[t]) * jd;
         curv += jd * jd;
+      }
+    }
+    // ---- one step of iterative refinement of the whole QP solution (CPMPC_CREATE_REFINE_QP; see the block after
+    // sweep 2 in mpc_fused_body.inc for the why): residuals of the terminal rows and of stationarity in the ORIGINAL
+    // data at the recovered (du, dx), the adjoint walked back through Phi^T; a second solve with the same factors;
+    // du, dx and the directional quantities replaced by the corrected ones.  Two more passes over the workspace.
+    if constexpr (sizeof(R) == 8 && !kWidened) {
+      if (a.refine_qp) {
+        R viol[NX], lamv[NX];
+#pragma unroll
+        for (int t = 0; t < NX; ++t) {
+          const R rT = Rw[t] * (dx[t] + e_term[t]);
+          const bool cost = Dg[t] != R(0);
+          lamv[t] = Rw[t] * (cost ? rT : q[t]);  // the adjoint at the terminal node, diag(Rw) mult
+          viol[t] = cost ? R(0) : rT;
+        }
+        R rho2[NX];
+#pragma unroll
+        for (int t = 0; t < NX; ++t) rho2[t] = R(0);
+        {  // descending: rstat_k = (T du)_k + g_k + Gamma_k . lambda_s, gw'_k = rstat_k - ups_k gw'_{k+1}, rho' += w_k gw'_k / d_k
+          R gw_next = R(0);
+          R du_hi = R(0), du_cur = a.dzu[(int64_t)(N - 1) * st + p];
+          R u_hi = R(0), u_cur = a.zu[(int64_t)(N - 1) * st + p];
+          int k2 = N - 1;
+          for (int s = S - 2; s >= 0; --s) {
+            for (int i = SP - 1; i >= 0; --i, --k2) {
+              const bool inner = k2 < N - 1;
+              const R du_lo = (k2 > 0) ? a.dzu[(int64_t)(k2 - 1) * st + p] : R(0);
+              const R u_lo = (k2 > 0) ? a.zu[(int64_t)(k2 - 1) * st + p] : u_prev;
+              R g = wu2 * u_cur + wd2 * (u_cur - u_lo);
+              if (inner) g += wd2 * (u_cur - u_hi);
+              R G[NX], Wr[NX];
+              unpack<R, NX>(a.Gam[(int64_t)k2 * st + p], G);
+              unpack<R, NX>(a.Wk[(int64_t)k2 * st + p], Wr);
+              V4 T = a.Tk[(int64_t)k2 * st + p];
+              R rstat = (wu2 + lam + wd2 * ((inner ? R(1) : R(0)) + R(1))) * du_cur - wd2 * du_lo + g;
+              if (inner) rstat -= wd2 * du_hi;
+#pragma unroll
+              for (int m = 0; m < NX; ++m) rstat += G[m] * lamv[m];
+              const R gw2 = rstat - T.y * gw_next;
+              const R t2 = gw2 * T.z;
+#pragma unroll
+              for (int m = 0; m < NX; ++m) rho2[m] += Wr[m] * t2;
+              T.x = gw2;
+              a.Tk[(int64_t)k2 * st + p] = T;
+              gw_next = gw2;
+              du_hi = du_cur;
+              du_cur = du_lo;
+              u_hi = u_cur;
+              u_cur = u_lo;
+            }
+            R ln[NX];
+#pragma unroll
+            for (int c = 0; c < NX; ++c) ln[c] = R(0);
+#pragma unroll
+            for (int r = 0; r < NX; ++r) {
+              R row[NX];
+              unpack<R, NX>(a.Phi[(int64_t)(NX * s + r) * st + p], row);
+#pragma unroll
+              for (int c = 0; c < NX; ++c) ln[c] += row[c] * lamv[r];
+            }
+#pragma unroll
+            for (int c = 0; c < NX; ++c) lamv[c] = ln[c];
+          }
+        }
+        R dq[NX];
+        {  // (S + Dg) dq = viol - rho' with the factors of the first solve
+          R y[NX];
+#pragma unroll
+          for (int i = 0; i < NX; ++i) {
+            R v = viol[i] - rho2[i];
+#pragma unroll
+            for (int m = 0; m < i; ++m) v -= Lm[i][m] * y[m];
+            y[i] = v;
+          }
+#pragma unroll
+          for (int i = NX - 1; i >= 0; --i) {
+            R v = y[i] / dv[i];
+#pragma unroll
+            for (int m = i + 1; m < NX; ++m) v -= Lm[m][i] * dq[m];
+            dq[i] = v;
+          }
+        }
+        // ascending: the correction of the step, applied; the directional quantities from the corrected step
+        gd = R(0);
+        curv = R(0);
+        dz_inf = R(0);
+        R ddx[NX];
+#pragma unroll
+        for (int t = 0; t < NX; ++t) {
+          ddx[t] = R(0);  // dx_0 = -c_init is exact
+          dz_inf = nan_max(dz_inf, Math<R>::fabs(ci[t]));
+        }
+        R ddu_prev = R(0), du_prev2 = R(0), ups_prev2 = R(0);
+        int k3 = 0;
+        for (int s = 0; s + 1 < S; ++s) {
+          R acc[NX];
+#pragma unroll
+          for (int r = 0; r < NX; ++r) {
+            R row[NX];
+            unpack<R, NX>(a.Phi[(int64_t)(NX * s + r) * st + p], row);
+            R v = R(0);
+#pragma unroll
+            for (int m = 0; m < NX; ++m) v += row[m] * ddx[m];
+            acc[r] = v;
+          }
+          for (int i = 0; i < SP; ++i, ++k3) {
+            R G[NX], Wr[NX];
+            unpack<R, NX>(a.Gam[(int64_t)k3 * st + p], G);
+            unpack<R, NX>(a.Wk[(int64_t)k3 * st + p], Wr);
+            const V4 T = a.Tk[(int64_t)k3 * st + p];
+            R wq = Wr[0] * dq[0];
+#pragma unroll
+            for (int m = 1; m < NX; ++m) wq += Wr[m] * dq[m];
+            const R ddu = -(T.x + wq) * T.z - ups_prev2 * ddu_prev;
+            const R du = a.dzu[(int64_t)k3 * st + p] + ddu;
+            a.dzu[(int64_t)k3 * st + p] = du;
+            dz_inf = nan_max(dz_inf, Math<R>::fabs(du));
+#pragma unroll
+            for (int r = 0; r < NX; ++r) acc[r] += G[r] * ddu;
+            gd += T.w * du;
+            const R jd = a.wd * (du_prev2 - du);
+            curv += wu2 * du * du + jd * jd + lam * du * du;
+            ddu_prev = ddu;
+            du_prev2 = du;
+            ups_prev2 = T.y;
+          }
+          R xn[NX];
+          unpack<R, NX>(a.dzx[(int64_t)(s + 1) * st + p], xn);
+#pragma unroll
+          for (int t = 0; t < NX; ++t) {
+            ddx[t] = acc[t];
+            xn[t] += acc[t];
+            dz_inf = nan_max(dz_inf, Math<R>::fabs(xn[t]));
+          }
+          a.dzx[(int64_t)(s + 1) * st + p] = pack<R, NX>(xn);
+#pragma unroll
+          for (int t = 0; t < NX; ++t) dx[t] = xn[t];
+        }
+#pragma unroll
+        for (int t = 0; t < NX; ++t) {
+          if (Dg[t] != R(0)) {
+            const R jd = Rw[t] * dx[t];
+            gd += (Rw[t] * e_term[t]) * jd;
+            curv += jd * jd;
+          }
+        }
       }
     }
   }

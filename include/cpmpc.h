@@ -144,12 +144,12 @@ void cpmpc_destroy(cpmpc_solver* s);
  *              extended-precision arbiter on every lane that is off; "at fault" = beyond 1e-5 and more than twice as far
  *              from the extended-precision answer as the double CPU check):
  *                 u_cost_weight >= 0.05:  0 of 1 798 144 lanes at fault, refined or not;
- *                 u_cost_weight <  0.05:  144 of 1 374 208 without the refinement, 16 with it (7 of those in the split
- *                                         pipeline, which does not have it; the rest are runs into the +-300 N clamp);
+ *                 u_cost_weight <  0.05:  144 of 1 374 208 without the refinement, 9 with it (two definitions whose
+ *                                         controls run into the +-300 N clamp, where the retraction is not smooth);
  *                 and, whatever the weights, definitions whose friction the explicit RK4 cannot follow (v_mu_b = 1e-7
  *                 with mu_b > 0: a slope of 1e5..1e6 1/s against a stability limit of 280 1/s at 10 ms; |Phi| reaches
  *                 1e4 per interval, the terminal system's condition 1e18): 281 of 923 648 lanes, 72 with it.
- *              Ignored by CPMPC_F32 handles and by the split pipeline; cpmpc_refines_qp() tells what a handle does. */
+ *              Both pipelines; ignored by CPMPC_F32 handles.  cpmpc_refines_qp() tells what a handle does. */
 #define CPMPC_CREATE_ALLOW_LONG_HORIZON 1u
 #define CPMPC_CREATE_REFINE_QP 2u
 #define CPMPC_CREATE_NO_REFINE_QP 4u

@@ -170,6 +170,13 @@ def test_refine_qp_flag_keeps_parity_and_tightens_the_qp(pkg, orc):
         res[refine] = (u, float(np.median(err)))
     assert np.abs(res[True][0] - res[False][0]).max() < 1e-6
     assert not np.array_equal(res[True][0], res[False][0])          # it is another kernel
+    # the split pipeline refines too, and agrees with the fused one
+    opt = pkg.BatchOptimization(pkg.default_params(**NO_TOL), max_batch=B, dtype=torch.float64, device=0, refine_qp=True)
+    opt.set_pipeline("split")
+    o = opt.step(T(x), DYN_UI, 0.0)
+    u_split = o.u.cpu().numpy()
+    assert (np.abs(u_split - u_cpu).max(axis=0) < 1e-5).all() and (o.status.cpu().numpy() == st_cpu).all()
+    assert np.abs(u_split - res[True][0]).max() < 1e-6
     f32 = pkg.BatchOptimization(pkg.default_params(**NO_TOL), max_batch=64, dtype=torch.float32, device=0, refine_qp=True)
     assert torch.isfinite(f32.step(T(x[:, :64], torch.float32), DYN_UI, 0.0).u).all()
     assert not f32.refines_qp
@@ -204,7 +211,7 @@ def test_fuzz_with_the_extended_precision_arbiter(pkg, orc):
         err = np.abs(u_g - u_c).max(axis=0)
         cls = "stiff" if (dyn[4] > 0.0 and dyn[5] < 1e-3) else ("free_controls" if over["u_cost_weight"] < 0.05 else "regular")
         lanes[cls] += B
-        assert opt.refines_qp == (over["u_cost_weight"] < 0.05) or opt.pipeline() == "split"
+        assert opt.refines_qp == (over["u_cost_weight"] < 0.05)
         idx = np.nonzero((err > 1e-5) | (st_g != st_c) | (it_g != it_c))[0]
         if idx.size:
             u_ld = orc.step_batch_cold_ld(orc.default_opt_params(**over), dyn, sp, x0[:, idx])[0]
