@@ -1,28 +1,27 @@
 """Where the fused SQP kernel spends its time: builds the library with -DCPMPC_FUSED_TIMING (shader-clock
 counters per phase, see CPMPC_TICK in csrc/mpc_fused.hpp) into tools/_build/ and runs the benchmark workload
-once.  Run from the repo root on a GPU box:  python tools/phase_timing.py [f32|f64]   (`--build-only` compiles the
-timing library here, where there is no GPU, so that it travels to the box)"""
+once.  Run from the repo root on a GPU box:  python tools/phase_timing.py [f32|f64] [--refine-qp]   (`--build-only`
+compiles the timing library here, where there is no GPU, so that it travels to the box)"""
 import os, subprocess, sys, ctypes, importlib, numpy as np, torch
 sys.path.insert(0, '.')
 _LIB = os.path.abspath("tools/_build/lib_timing/libcpmpc.so")
-_SRC = "cart-pole-mpc_amd/csrc/cpmpc_api.hip"
-if not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(
-        os.path.getmtime(os.path.join("cart-pole-mpc_amd/csrc", f)) for f in os.listdir("cart-pole-mpc_amd/csrc")):
-    os.makedirs(os.path.dirname(_LIB), exist_ok=True)
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize",
-                           "-shared", "-fPIC", "-DCPMPC_FUSED_TIMING", "-Iinclude", "-o", _LIB, _SRC])
+os.environ["CPMPC_LIB"] = _LIB   # before the package is imported: capi fixes its library path at import
+build = importlib.import_module("cart-pole-mpc_amd.build")
+assert build.build_variant("timing", ["-DCPMPC_FUSED_TIMING"]) == _LIB   # the five translation units with the phase counters
 if "--build-only" in sys.argv:
     sys.exit(0)
 DT = torch.float64 if "f64" in sys.argv else torch.float32
 os.environ["CPMPC_LIB"] = _LIB
 pkg = importlib.import_module("cart-pole-mpc_amd")
-lib = ctypes.CDLL(os.environ["CPMPC_LIB"])
+lib = pkg.capi.load()
+assert os.path.samefile(pkg.capi.LIB_PATH, _LIB), (pkg.capi.LIB_PATH, _LIB)
 DYN_UI = [1.0, 0.1, 0.25, 9.81, 0.05, 0.1, 0.02, 0.8, 100.0]
 rng = np.random.default_rng(1000)
 B = 262144
 x0 = np.stack([rng.uniform(-0.6, 0.6, B), rng.uniform(-np.pi, np.pi, B), rng.uniform(-1, 1, B), rng.uniform(-3, 3, B)])
 x0t = torch.tensor(x0, dtype=DT, device='cuda')
-opt = pkg.BatchOptimization(pkg.default_params(max_iterations=5, relative_exit_tol=0.0, absolute_first_derivative_tol=0.0), max_batch=B, dtype=DT, device=0)
+opt = pkg.BatchOptimization(pkg.default_params(max_iterations=5, relative_exit_tol=0.0, absolute_first_derivative_tol=0.0), max_batch=B, dtype=DT, device=0,
+                            refine_qp=("--refine-qp" in sys.argv) or None)
 opt.set_pipeline("fused")
 names = ["linearize", "d-chain", "sweep1 local pass", "boundary chain + combine", "group sums + rows + LDLT + sweep1b", "sweep2", "penalty + line search", "accept + prologue + epilogue"]
 buf = (ctypes.c_ulonglong * 8)()
@@ -30,7 +29,8 @@ for rep in range(3):
     opt.reset()
     opt.step(x0t, DYN_UI, 0.0)
     torch.cuda.synchronize()
-    lib.cpmpc_debug_phase_cycles(buf)
+    rc = lib.cpmpc_debug_phase_cycles(buf)
+    assert rc == 0, "cpmpc_debug_phase_cycles failed (rc %d): is %s a -DCPMPC_FUSED_TIMING build?" % (rc, _LIB)
 tot = sum(buf)
 print("dtype", DT)
 for n, v in zip(names, buf):
