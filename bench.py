@@ -485,6 +485,10 @@ def variants(torch, pkg, args, tdt, dev, local_rank, x0, B):
     except Exception as exc:  # noqa: BLE001
         res["per_problem_params"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     try:
+        res["shards_on_streams"] = split_streams_variant(torch, pkg, args, dev, local_rank, B)
+    except Exception as exc:  # noqa: BLE001
+        res["shards_on_streams"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    try:
         res["single_controller_facade"] = single_controller_latency(pkg)
     except Exception as exc:  # noqa: BLE001
         res["single_controller_facade"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
@@ -552,6 +556,57 @@ def per_problem_variant(torch, pkg, args, dev, local_rank, B, lanes=4096, steps=
         rec["parity_vs_cpu_check"] = ps
         res[name] = rec
         del opt
+    return res
+
+
+def split_streams_variant(torch, pkg, args, dev, local_rank, B, steps=20):
+    """Shards of the batch on concurrent streams of ONE GPU (never `value`): the headline's cold-start re-plan with the
+    batch held by 2 / 4 handles of B / parts problems, each stepped on its own stream with no synchronisation between the
+    shards.  A step is prepare (HBM-bound) -> fused SQP kernel (issue-bound, ending in a tail of partly filled compute
+    units) -> finalize (HBM-bound); free-running shards drift apart, so the memory-bound kernels and the tail of one shard
+    overlap the arithmetic of another.  (Splitting ONE step into column ranges that fork from and join the caller's
+    stream was built and measured in round 4: +0.2 % fp64, -1.5..-5 % fp32 -- ranges that start together reach every phase
+    together -- and removed; the gain needs the shards to be independent across steps, which separate handles give.)
+    Wall-clock re-plans/s per setting and that the controls are bitwise those of the single handle."""
+    over = dict(max_iterations=args.iters, relative_exit_tol=0.0, absolute_first_derivative_tol=0.0)
+    x_np = synth_states(SEED, B)
+    res = {"note": "cold start, %d iterations, exits disabled, u + predicted written; parts = 1 is the headline's "
+                   "configuration measured here the same way (wall clock over %d steps)" % (args.iters, steps)}
+    for name, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        rec, u_ref = {}, None
+        for parts in (1, 2, 4):
+            Bp = B // parts
+            opts = [pkg.BatchOptimization(pkg.default_params(**over), max_batch=Bp, dtype=dt, device=local_rank) for _ in range(parts)]
+            for o in opts:
+                o.set_pipeline(args.pipeline)
+            xs = [torch.tensor(x_np[:, i * Bp:(i + 1) * Bp], dtype=dt, device=dev) for i in range(parts)]
+            outs = [pkg.BatchOutputs() for _ in range(parts)]
+            streams = [torch.cuda.Stream(device=dev) for _ in range(parts)]
+
+            def step():
+                for o, x, out, st in zip(opts, xs, outs, streams):
+                    with torch.cuda.stream(st):
+                        o.reset()
+                        o.step(x, DYN_UI, 0.0, want_predicted=True, out=out)
+
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize()
+            el = (time.perf_counter() - t0) / steps
+            r = {"re-plans/s": Bp * parts / el, "ms_per_step": el * 1e3}
+            u = torch.cat([o.u for o in outs], dim=1)
+            if parts == 1:
+                u_ref = u
+            else:
+                r["bitwise_equal_to_one_handle"] = bool(torch.equal(u, u_ref[:, :Bp * parts]))
+                r["speedup"] = rec["parts_1"]["ms_per_step"] / r["ms_per_step"]
+            rec["parts_%d" % parts] = r
+            del opts, xs, outs
+        res[name] = rec
     return res
 
 

@@ -264,9 +264,15 @@ class BatchOptimization:
     def refines_qp(self):
         return bool(capi.load().cpmpc_refines_qp(self._h))
 
-    def set_compaction(self, first_iterations=3, next_iterations=1):
+    def set_compaction(self, first_iterations=2, next_iterations=1):
         """Staging of the fused pipeline when exit tolerances are enabled (0, 0 = one launch).  Speed only."""
         capi.check(capi.load().cpmpc_set_compaction(self._h, int(first_iterations), int(next_iterations)))
+
+    def stage_plan(self):
+        """Boundaries [0, ..., max_iterations] of the launches of the fused kernel in the last step (cpmpc_get_stage_plan)."""
+        buf = (C.c_int32 * 32)()
+        n = capi.load().cpmpc_get_stage_plan(self._h, buf, 32)
+        return [int(buf[i]) for i in range(n + 1)] if n >= 0 else []
 
     def pipeline(self):
         return {capi.PIPELINE_SPLIT: "split", capi.PIPELINE_FUSED: "fused"}[capi.load().cpmpc_get_pipeline(self._h)]

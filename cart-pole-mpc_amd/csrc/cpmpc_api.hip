@@ -276,6 +276,17 @@ static int create_impl(const cpmpc_params* params, const cpmpc_solver_opts* opts
     (void)hipGetLastError();
     s->active = nullptr;  // staging stays off for this handle (same results, single launch)
   }
+  // histogram of iterations per problem, device -> host through mapped memory (the plan of the stages; optional as well)
+  const size_t fb_bytes = (size_t)kHostSlots * kFbReporters * (kFbBins + 1) * sizeof(int32_t);
+  if (s->active != nullptr &&
+      hipHostMalloc((void**)&s->fb_host, fb_bytes, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+      hipHostGetDevicePointer((void**)&s->fb_host_dev, s->fb_host, 0) == hipSuccess) {
+    memset(s->fb_host, 0, fb_bytes);
+  } else {
+    (void)hipGetLastError();
+    if (s->fb_host) (void)hipHostFree(s->fb_host);
+    s->fb_host = s->fb_host_dev = nullptr;  // the fixed plan (2 iterations, then 1 at a time) for every step
+  }
   *out = s;
   return CPMPC_OK;
 }
@@ -322,6 +333,7 @@ extern "C" void cpmpc_destroy(cpmpc_solver* s) {
   }
   if (s->ev_last) (void)hipEventDestroy(s->ev_last);
   if (s->active) (void)hipFree(s->active);
+  if (s->fb_host) (void)hipHostFree(s->fb_host);
   delete s;
 }
 
@@ -434,6 +446,122 @@ extern "C" int cpmpc_set_compaction(cpmpc_solver* s, int first_iterations, int n
   s->stage_auto = false;  // an explicit setting applies to every batch size
   return CPMPC_OK;
 }
+// ---- the stages of the fused pipeline for one step ---------------------------------------------------------------------
+// The kernel runs bounds[i+1] - bounds[i] iterations per launch; between launches the problems still iterating are
+// compacted into dense waves (engine_impl.hpp: step_batch_impl).  Where to cut is a question of speed only.
+//  * exits disabled, or a batch of at most one round of resident waves: one launch;
+//  * an explicit cpmpc_set_compaction(first, next): first, then next at a time;
+//  * default: from the histogram of iterations per problem of the most recent step whose finalize_kernel has finished
+//    (host-mapped memory, read without synchronisation; a step queued but not finished simply does not count yet), by
+//    dynamic programming over the cuts with this cost model, in units of one wave's time for one iteration:
+//      - a stage from iteration a to b runs surv(a) / ppw waves (surv(j) = problems that need more than j iterations);
+//        a wave lasts until the slowest of its ppw problems stops: sum over j of 1 - (1 - surv(a+j) / surv(a))^ppw;
+//      - the stage takes max(wave-iterations / resident waves, its longest wave) + one launch and compaction (7 us);
+//      - a stage with at most one round of resident waves left runs to the end (the kernel's own rule);
+//    a plan that comes out as ONE launch although the histogram says nearly everybody (99.9 %) stops early gets one cut
+//    where they do: in a settled closed loop (everybody stops after the first iteration) that is a second, empty launch
+//    per tick (7 us), and it is what keeps a tick in which some controllers are disturbed from being bound by waves
+//    that one disturbed problem in sixteen keeps alive.  Before the first histogram: 2 iterations, then 1 at a time.
+int cpmpc_plan_stages(cpmpc_solver* s, int slot, int64_t B, bool exits, int* bounds) {
+  const int T = (int)s->params.max_iterations;
+  const int L = s->S - 1, ppw = 64 / L;
+  auto finish = [&](int n) {
+    s->last_plan_n = n;
+    for (int i = 0; i <= n; ++i) s->last_plan[i] = bounds[i];
+    return n;
+  };
+  bounds[0] = 0;
+  bounds[1] = T;
+  if (!exits || s->active == nullptr || T < 2) return finish(1);
+  auto fixed = [&](int first, int next) {  // `first` iterations, then `next` at a time (the last launch takes what is left)
+    if (first <= 0 || next <= 0 || T <= first) return finish(1);
+    int n = 1;
+    bounds[1] = first;
+    while (bounds[n] < T && n < kMaxStages) {
+      bounds[n + 1] = bounds[n] + next < T ? bounds[n] + next : T;
+      ++n;
+    }
+    bounds[n] = T;
+    return finish(n);
+  };
+  if (!s->stage_auto) return fixed(s->stage_first, s->stage_next);
+  // default: only batches beyond one round of resident waves (2 per SIMD) are staged at all -- a smaller one ends with
+  // its slowest wave either way
+  if ((B * (int64_t)L + 63) / 64 <= 2048) return finish(1);
+  if (s->fb_host == nullptr || T > kMaxStages) return fixed(s->stage_first, s->stage_next);
+  // the counts of the reporting workgroups that carry the same step's stamp as the first one (a step still running has
+  // stamped only some: they wait for a later plan)
+  const int32_t* fb = s->fb_host + (size_t)slot * kFbReporters * (kFbBins + 1);
+  const int seq = __atomic_load_n(&fb[kFbBins], __ATOMIC_ACQUIRE);
+  double hist[kFbBins], n_hist = 0.0;
+  for (int b = 0; b < kFbBins; ++b) hist[b] = 0.0;
+  for (int r = 0; seq != 0 && r < s->fb_reporters[slot]; ++r) {
+    const int32_t* rep = fb + (size_t)r * (kFbBins + 1);
+    if (__atomic_load_n(&rep[kFbBins], __ATOMIC_ACQUIRE) != seq) continue;
+    for (int b = 0; b < kFbBins; ++b) {
+      const double c = (double)__atomic_load_n(&rep[b], __ATOMIC_RELAXED);
+      hist[b] += c;
+      n_hist += c;
+    }
+  }
+  if (seq == 0 || n_hist <= 0.0) return fixed(s->stage_first, s->stage_next);  // nothing to plan from yet
+  // surv[j]: expected problems of THIS batch needing more than j iterations, j = 0 .. T
+  double surv[kMaxStages + 1];
+  const double scale = (double)B / n_hist;
+  for (int j = 0; j <= T; ++j) {
+    double above = 0.0;
+    for (int b = j + 1; b < kFbBins; ++b) above += hist[b];
+    surv[j] = j < T ? above * scale : 0.0;
+  }
+  surv[0] = (double)B;
+  const double resident = s->esize == 8 ? 1024.0 : 2048.0;   // waves of the fused kernel the machine holds (1 / 2 per SIMD)
+  const double launch = 0.14 * 40.0 / (double)s->N;           // 7 us in units of one wave-iteration (50 us at N = 40)
+  const double run_out = 2048.0 * (double)ppw;                // the kernel's run_out_below
+  double best[kMaxStages + 2];
+  int next_cut[kMaxStages + 2];
+  best[T] = 0.0;
+  for (int a = T - 1; a >= 0; --a) {
+    best[a] = 1e300;
+    next_cut[a] = T;
+    for (int b = T; b > a; --b) {
+      if (a > 0 && surv[a] <= run_out && b != T) continue;   // such a stage runs to the end by itself
+      double wave_iters = 0.0, longest = 0.0;
+      for (int j = 0; a + j < b; ++j) {
+        const double q = surv[a] > 0.0 ? surv[a + j] / surv[a] : 0.0;
+        wave_iters += 1.0 - std::pow(1.0 - (q > 1.0 ? 1.0 : q), (double)ppw);
+        if (surv[a + j] >= 1.0) longest = (double)(j + 1);
+      }
+      wave_iters *= surv[a] / (double)ppw;
+      const double thr = wave_iters / resident;
+      const double cost = (thr > longest ? thr : longest) + launch + (b < T ? best[b] : 0.0);
+      if (cost < best[a] - 1e-12) {
+        best[a] = cost;
+        next_cut[a] = b;
+      }
+    }
+  }
+  int n = 0;
+  for (int a = 0; a < T && n < kMaxStages; a = next_cut[a]) bounds[++n] = next_cut[a];
+  bounds[n] = T;
+  if (n == 1) {  // the insurance cut (see above)
+    for (int j = 1; j < T; ++j)
+      if (surv[j] <= 0.001 * (double)B) {
+        bounds[1] = j;
+        bounds[2] = T;
+        n = 2;
+        break;
+      }
+  }
+  return finish(n);
+}
+
+extern "C" int cpmpc_get_stage_plan(const cpmpc_solver* s, int32_t* bounds, int capacity) {
+  if (!s || !bounds || capacity < 2) return -1;
+  const int n = s->last_plan_n < capacity - 1 ? s->last_plan_n : capacity - 1;
+  for (int i = 0; i <= n; ++i) bounds[i] = s->last_plan[i];
+  return n;
+}
+
 extern "C" int cpmpc_get_pipeline(const cpmpc_solver* s) {
   if (!s) return -1;
   return use_fused(s) ? CPMPC_PIPELINE_FUSED : CPMPC_PIPELINE_SPLIT;

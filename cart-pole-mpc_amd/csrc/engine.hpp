@@ -36,6 +36,7 @@ struct ProfSpan {
 // owns kHostSlots of them so that a large host-pointer step runs as a pipeline of chunks: while the CPU scatters chunk k's
 // results into the caller's arrays, chunk k+1 is copying back and chunk k+2 is in the kernels.
 constexpr int kHostSlots = 3;
+constexpr int kMaxStages = 16;  // launches of the fused kernel per step at most (the plan of a step's stages)
 struct HostSlot {
   void* dev = nullptr;
   void* pin = nullptr;
@@ -80,9 +81,21 @@ struct cpmpc_solver {
   int pipeline = CPMPC_PIPELINE_AUTO;
   bool refine_qp = false;  // CPMPC_CREATE_REFINE_QP: the double fused kernels refine the whole QP solution once
   // staged fused pipeline (compaction of the still-active problems between stages); 0/0 = single launch
-  int stage_first = 3, stage_next = 1;
+  // default 2 / 1 (round 4, tools/steady_state.py): in the warm-started closed loop most problems stop after one or two
+  // iterations, so compacting after two pays (fp32 at the reference's tolerances 1.47 -> 1.34 ms per tick, the swing-up
+  // transient -4 %); a stage that finds nobody left costs one empty launch (7 us)
+  int stage_first = 2, stage_next = 1;
   bool stage_auto = true;  // default: stage only batches larger than one round of resident waves
   int32_t* active = nullptr;  // [cap] compacted problem indices, then two counters
+  // the stages of the fused pipeline, planned per step (stage_auto) from the histogram of iterations per problem that
+  // finalize_kernel left in host-mapped memory after an earlier step: per host slot, kFbReporters blocks of kFbBins + 1
+  // ints (a reporting workgroup's counts + the sequence number of its step)
+  int32_t* fb_host = nullptr;
+  int32_t* fb_host_dev = nullptr;  // the device's address of fb_host
+  int fb_seq[kHostSlots] = {0, 0, 0};
+  int fb_reporters[kHostSlots] = {0, 0, 0};  // reporting workgroups of the last step launched on the slot
+  int last_plan[kMaxStages + 1] = {0};  // boundaries of the stages of the last step (cpmpc_get_stage_plan)
+  int last_plan_n = 0;
 };
 
 
@@ -90,6 +103,8 @@ struct cpmpc_solver {
 CPMPC_HIDDEN void span_begin(cpmpc_solver* s, int kernel, hipStream_t stream, ProfSpan* cur);
 CPMPC_HIDDEN void span_end(cpmpc_solver* s, hipStream_t stream, ProfSpan* cur);
 CPMPC_HIDDEN int ensure_slot(cpmpc_solver* s, int slot, size_t bytes);
+// the stages of the fused pipeline for a step of B problems: bounds[0] = 0 < ... < bounds[n] = max_iterations, returns n
+CPMPC_HIDDEN int cpmpc_plan_stages(cpmpc_solver* s, int slot, int64_t B, bool exits, int* bounds);
 // run fn(i) for i in [0, n) on the library's worker threads (the calling thread takes part); returns when all are done
 CPMPC_HIDDEN void host_parallel_for(int64_t n, void (*fn)(int64_t i, void* ctx), void* ctx);
 

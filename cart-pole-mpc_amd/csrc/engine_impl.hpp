@@ -220,23 +220,22 @@ static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* 
     // as its slowest problem (closed loop, measured: 4.3 iterations per problem, 7.7 per wave of 16).  The kernel
     // is restartable -- all solver state is in the workspace between launches -- so it runs in stages and the
     // problems still iterating are compacted into dense waves in between.  Results are bitwise those of a single
-    // launch: a problem's arithmetic does not depend on the lanes it occupies.
+    // launch: a problem's arithmetic does not depend on the lanes it occupies.  Where the stages end is planned per
+    // step (cpmpc_plan_stages: an explicit cpmpc_set_compaction, or from how many iterations the problems of an earlier
+    // step needed).
     const int total = (int)s->params.max_iterations;
     const bool exits = s->params.relative_exit_tol > 0.0 || s->params.absolute_first_derivative_tol > 0.0;
-    bool staged = exits && s->stage_first > 0 && s->stage_next > 0 && total > s->stage_first;
-    // a batch that fits the machine in one round of resident waves (2 per SIMD) ends with its slowest wave either
-    // way: staging would only add launches
-    if (s->stage_auto && (B * (int64_t)(s->S - 1) + 63) / 64 <= 2048) staged = false;
-    if (s->active == nullptr) staged = false;  // no index list (allocation failed at creation): single launch, same results
+    int bounds[kMaxStages + 1];
+    const int n_stages = cpmpc_plan_stages(s, slot, B, exits, bounds);
     a.active_list = nullptr;
     a.active_count = nullptr;
     a.iter_cap = total;
     a.run_out_below = (int64_t)2048 * (64 / (s->S - 1));  // problems in one round of resident waves (2 per SIMD)
     span_begin(s, CPMPC_KERNEL_FUSED, stream, &sp);
-    launch_fused<R, M>(a, s->S - 1, s->SP, staged ? s->stage_first : total, s->refine_qp, stream);
+    launch_fused<R, M>(a, s->S - 1, s->SP, bounds[1], s->refine_qp, stream);
     span_end(s, stream, &sp);
-    int stage = 0;
-    for (int done = s->stage_first; staged && done < total; done += s->stage_next, ++stage) {
+    for (int stage = 0; stage + 1 < n_stages; ++stage) {
+      const int done = bounds[stage + 1];
       int32_t* const counters = s->active + s->cap + 2 * slot;  // a pair per host slot: chunks of a pipelined host step run concurrently
       int32_t* count = counters + (stage & 1);                  // two counters: this compaction and the one before
       a.prev_count = stage ? counters + ((stage - 1) & 1) : nullptr;
@@ -249,7 +248,7 @@ static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* 
                          (const int32_t*)(a.ist + (size_t)IS_ITERS * (size_t)s->cap), total, B, s->active + col0, count);
       a.active_list = s->active + col0;
       a.active_count = count;
-      const int k = (total - done < s->stage_next) ? (total - done) : s->stage_next;
+      const int k = bounds[stage + 2] - done;
       launch_fused<R, M>(a, s->S - 1, s->SP, k, s->refine_qp, stream);
       span_end(s, stream, &sp);  // the span is closed (its events recycled) before any early return
       if (memset_rc != hipSuccess) {
@@ -268,6 +267,15 @@ static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* 
     }
   }
 
+  // the histogram of iterations per problem goes back to the host for the plan of a later step (default staging only)
+  if (use_fused(s) && s->stage_auto && s->fb_host != nullptr && s->active != nullptr &&
+      (s->params.relative_exit_tol > 0.0 || s->params.absolute_first_derivative_tol > 0.0)) {
+    const int64_t groups = (B + CPMPC_PF_BLOCK - 1) / CPMPC_PF_BLOCK;
+    a.fb_stride = (int)((groups + kFbReporters - 1) / kFbReporters);
+    a.fb_host = s->fb_host_dev + (size_t)slot * kFbReporters * (kFbBins + 1);
+    a.fb_seq = ++s->fb_seq[slot];
+    s->fb_reporters[slot] = (int)((groups + a.fb_stride - 1) / a.fb_stride);
+  }
   span_begin(s, CPMPC_KERNEL_FINALIZE, stream, &sp);
   hipLaunchKernelGGL((finalize_kernel<R, M>), dim3((unsigned)((B + CPMPC_PF_BLOCK - 1) / CPMPC_PF_BLOCK)), dim3(CPMPC_PF_BLOCK), 0, stream, a);
   span_end(s, stream, &sp);

@@ -154,6 +154,10 @@ struct SolverArgs {
   const int32_t* prev_count;  // active problems at the previous compaction (nullptr: prev_total)
   int64_t prev_total;
   int remaining;           // iterations still to run, this stage included
+  // feedback for the host's staging plan (finalize_kernel): histogram of this step's iterations per problem
+  int32_t* fb_host;        // host-mapped [reporter][kFbBins + 1]: a workgroup's histogram, then fb_seq (written last); nullptr: off
+  int fb_seq;
+  int fb_stride;           // workgroups blockIdx.x % fb_stride == 0 report
   typename M::Consts consts;  // shared model constants (used when dyn == nullptr)
   // outputs, packed [field][B] (nullable)
   R* u_out;
@@ -1193,8 +1197,33 @@ template <typename R, typename M>
 __global__ __launch_bounds__(CPMPC_PF_BLOCK) void finalize_kernel(const SolverArgs<R, M> a) {
   constexpr int NX = M::NX;
   const unsigned p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= a.B) return;
   const int64_t st = a.stride;
+  if (a.fb_host != nullptr && blockIdx.x % (unsigned)a.fb_stride == 0u) {
+    // How many problems ran how many iterations: the host reads it (no copy, no synchronisation: host-mapped memory)
+    // before a later step and plans that step's stages from it.  No device-wide reduction: every fb_stride-th workgroup
+    // writes its own 16 counts and the host adds them up (at most 256 x 16 ints).  (A first version summed all
+    // workgroups with device-scope atomics and published the total behind a system-scope release: 29 -> 92 us.)
+    __shared__ int bins[kFbBins];
+    if (threadIdx.x < kFbBins) bins[threadIdx.x] = 0;
+    __syncthreads();
+    int bin = -1;
+    if (p < a.B) {
+      const int it = a.ist[IS_ITERS * st + p];
+      bin = it < kFbBins - 1 ? (it < 0 ? 0 : it) : kFbBins - 1;
+    }
+    for (int b = 0; b < kFbBins; ++b) {
+      const unsigned long long m = __ballot(bin == b);
+      if (m != 0ull && (threadIdx.x & 63) == 0) atomicAdd(&bins[b], __popcll(m));
+    }
+    __syncthreads();
+    int32_t* const dst = a.fb_host + (size_t)(blockIdx.x / (unsigned)a.fb_stride) * (kFbBins + 1);
+    // relaxed stores, no system-scope fence: a release at system scope writes the whole L2 back (this kernel's own
+    // outputs: 29 -> 94 us measured), and all the host needs is a hint -- a count read half-updated costs nothing but speed
+    if (threadIdx.x < kFbBins) __hip_atomic_store(&dst[threadIdx.x], bins[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&dst[kFbBins], a.fb_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (p >= a.B) return;
   const int64_t ob = a.B;  // outputs are packed [field][B]
   int status = a.ist[IS_STATUS * st + p];
   if (status == kTermNone) status = kTermMaxIterations;

@@ -419,9 +419,17 @@ enum { CPMPC_PIPELINE_AUTO = 0, CPMPC_PIPELINE_SPLIT = 1, CPMPC_PIPELINE_FUSED =
 int cpmpc_set_pipeline(cpmpc_solver* s, int mode);
 /* Fused pipeline with exit tolerances enabled: run `first_iterations` SQP iterations on every problem, then
  * compact the problems that are still iterating into dense waves before every further `next_iterations` (default
- * 3 and 1, applied to batches larger than one round of resident waves; an explicit call applies to every batch size;
- * 0 disables and gives the single launch).  A speed setting only: results do not change. */
+ * 2 and 1, applied to batches larger than one round of resident waves; an explicit call applies to every batch size;
+ * 0 disables and gives the single launch).  A speed setting only: results do not change.  Which staging is fastest
+ * depends on how the iteration counts are spread: tools/steady_state.py measures a workload under each. */
 int cpmpc_set_compaction(cpmpc_solver* s, int first_iterations, int next_iterations);
+/* Without an explicit cpmpc_set_compaction the stages are planned per step from how many iterations the problems of the
+ * most recent FINISHED step needed (a histogram finalize leaves in host-mapped memory; read without synchronisation):
+ * a settled closed loop, where every controller stops after one iteration, runs two launches instead of seven; a batch
+ * whose iteration counts spread gets a cut wherever enough problems have stopped to pay for a compaction.  Speed only.
+ * This reads back the plan of the last step: bounds[0] = 0 < ... < bounds[n] = max_iterations, returns n (the number of
+ * launches of the fused kernel), -1 on a bad argument. */
+int cpmpc_get_stage_plan(const cpmpc_solver* s, int32_t* bounds, int capacity);
 int cpmpc_get_pipeline(const cpmpc_solver* s); /* the one a step will actually use: SPLIT or FUSED */
 
 /* When enabled, every kernel launch of cpmpc_step_batch is bracketed by HIP events on the launch

@@ -127,6 +127,100 @@ def test_chunked_host_step_is_bitwise_the_unsplit_one(pkg, dtype):
         lib.cpmpc_destroy(many)
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_a_closed_loop_tick_can_be_captured_in_a_hip_graph(pkg, dtype):
+    """The device-pointer step and the plant step are kernel launches, memsets and event records on the caller's stream
+    and nothing else (no allocation, no host synchronisation, no host read of device data): a warm-started tick captured
+    once in a HIP graph and replayed gives the eager loop's states and controls bit for bit.  (What the capture bakes in:
+    the pointers, the batch size, and that problems [0, B) hold a previous solution -- so capture after the first step.)"""
+    B, ticks = 20000, 12     # large enough for the staged fused pipeline (compaction launches inside the capture)
+    rng = np.random.default_rng(5)
+    xs = np.stack([rng.uniform(-0.3, 0.3, B), np.pi / 2 + rng.uniform(-0.4, 0.4, B), rng.uniform(-0.5, 0.5, B), rng.uniform(-1, 1, B)])
+
+    def make():
+        sim = pkg.BatchSimulator(B, dtype=dtype, device=0)
+        sim.set_state(T(xs, dtype))
+        opt = pkg.BatchOptimization(pkg.default_params(), max_batch=B, dtype=dtype, device=0)
+        opt.set_compaction(2, 1)
+        return sim, opt, pkg.BatchOutputs()
+
+    def tick(sim, opt, out):
+        o = opt.step(sim.get_state(), DYN_UI, 0.0, want_predicted=True, want_stats=True, out=out)
+        sim.step(DYN_UI, 0.01, o.u[0])
+
+    sim, opt, out = make()
+    for _ in range(2 + ticks):
+        tick(sim, opt, out)
+    torch.cuda.synchronize()
+    want = [t.clone() for t in (sim.get_state(), out.u, out.predicted_states, out.status, out.iterations)]
+
+    sim, opt, out = make()
+    for _ in range(2):
+        tick(sim, opt, out)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            tick(sim, opt, out)    # recorded, not executed
+    torch.cuda.synchronize()
+    for _ in range(ticks):
+        graph.replay()
+    torch.cuda.synchronize()
+    got = (sim.get_state(), out.u, out.predicted_states, out.status, out.iterations)
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_stage_plan_follows_the_iteration_histogram_and_changes_no_result(pkg, dtype):
+    """Default staging of the fused pipeline: the plan of a step's launches comes from the histogram of iterations per
+    problem that the finalize kernel of an earlier, finished step left in host-mapped memory (cpmpc_get_stage_plan).
+    Before the first histogram: 2 iterations, then 1 at a time.  Once every controller stops after the same m iterations
+    (the settled closed loop: m = 1 in fp64): one launch of m iterations plus the insurance cut.  Whatever the plan, every
+    tick's controls, statuses and iteration counts are bit for bit those of the single launch."""
+    B, ticks = 40000, 250    # 2 500 waves: beyond one round of resident waves, so the default stages it
+    rng = np.random.default_rng(11)
+    xs = np.stack([rng.uniform(-0.05, 0.05, B), np.pi / 2 + rng.uniform(-0.05, 0.05, B), rng.uniform(-0.1, 0.1, B), rng.uniform(-0.1, 0.1, B)])
+    T8 = pkg.default_params().max_iterations
+
+    def make(single):
+        sim = pkg.BatchSimulator(B, dtype=dtype, device=0)
+        sim.set_state(T(xs, dtype))
+        opt = pkg.BatchOptimization(pkg.default_params(), max_batch=B, dtype=dtype, device=0)
+        if single:
+            opt.set_compaction(0, 0)
+        return sim, opt, pkg.BatchOutputs()
+
+    sa, oa, outa = make(False)
+    sb, ob, outb = make(True)
+    plans, uniform = [], []
+    for k in range(ticks):
+        o1 = oa.step(sa.get_state(), DYN_UI, 0.0, want_predicted=False, want_stats=True, out=outa)
+        o2 = ob.step(sb.get_state(), DYN_UI, 0.0, want_predicted=False, want_stats=True, out=outb)
+        plan = oa.stage_plan()
+        assert plan[0] == 0 and plan[-1] == T8 and all(b > a for a, b in zip(plan, plan[1:])), plan
+        assert ob.stage_plan() == [0, T8]
+        plans.append(plan)
+        torch.cuda.synchronize()    # the controller acts on u: the histogram of this tick is there for the next plan
+        for a, b in ((o1.u, o2.u), (o1.status, o2.status), (o1.iterations, o2.iterations), (o1.final_cost, o2.final_cost)):
+            assert torch.equal(a, b), k
+        lo, hi = int(o1.iterations.min().item()), int(o1.iterations.max().item())
+        uniform.append(lo if lo == hi else 0)
+        sa.step(DYN_UI, 0.01, o1.u[0])
+        sb.step(DYN_UI, 0.01, o2.u[0])
+    assert plans[0] == [0, 2] + list(range(3, T8 + 1))      # nothing to plan from yet
+    assert plans[1] != plans[0]                              # the first histogram has arrived
+    checked = 0
+    for k in range(1, ticks):
+        m = uniform[k - 1]                                   # the tick the plan of tick k was made from
+        if 0 < m < T8:
+            assert plans[k] == [0, m, T8], (k, m, plans[k])
+            checked += 1
+    if dtype == torch.float64:
+        assert uniform[-1] == 1 and checked > 5              # settled: SATISFIED_FIRST_ORDER_TOL after one iteration
+
+
 def test_out_buffers_of_the_other_precision_are_replaced_not_written_through(pkg):
     """BatchOptimization.step(out=...) reuses the caller's output tensors only if shape, dtype and device all match: a
     BatchOutputs filled by an fp32 optimizer handed to an fp64 one has the right SHAPES and half the bytes (an fp64 kernel

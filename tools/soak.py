@@ -24,6 +24,7 @@ ap.add_argument("--ticks", type=int, default=1000)
 ap.add_argument("--start", choices=["near-upright", "anywhere"], default="anywhere")
 ap.add_argument("--fo-tol", type=float, default=None, help="absolute_first_derivative_tol (reference default 1e-6)")
 ap.add_argument("--pipeline", choices=["auto", "split", "fused"], default="auto")
+ap.add_argument("--compaction", default=None, help="first:next iterations of the staged fused pipeline (cpmpc_set_compaction); default: the library's")
 ap.add_argument("--out", default=None)
 args = ap.parse_args()
 dt = torch.float32 if args.dtype == "f32" else torch.float64
@@ -38,6 +39,8 @@ sim.set_state(torch.tensor(x0, dtype=dt, device="cuda:0"))
 over = {} if args.fo_tol is None else {"absolute_first_derivative_tol": args.fo_tol}
 opt = pkg.BatchOptimization(pkg.default_params(**over), max_batch=B, dtype=dt, device=0)
 opt.set_pipeline(args.pipeline)
+if args.compaction:
+    opt.set_compaction(*(int(v) for v in args.compaction.split(":")))
 out = pkg.BatchOutputs()
 names = pkg.capi.TERM_NAMES
 hist_total = {}
