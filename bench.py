@@ -423,19 +423,19 @@ def variants(torch, pkg, args, tdt, dev, local_rank, x0, B):
     opt = pkg.BatchOptimization(p1, max_batch=B, dtype=tdt, device=local_rank)
     opt.set_pipeline(args.pipeline)
     out = pkg.BatchOutputs()
-    for _ in range(2):
+    for _ in range(3):
         opt.reset()
         opt.step(x0, DYN_UI, 0.0, want_predicted=True, want_stats=True, out=out)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    reps = 5
+    reps = 20
     for _ in range(reps):
         opt.reset()
         o = opt.step(x0, DYN_UI, 0.0, want_predicted=True, want_stats=True, out=out)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     st = o.status.cpu().numpy()
-    res["exits_enabled"] = {"re-plans/s": B / dt, "ms_per_step": dt * 1e3,
+    res["exits_enabled"] = {"re-plans/s": B / dt, "ms_per_step": dt * 1e3, "stage_plan": opt.stage_plan(),
                             "mean_iterations": float(o.iterations.float().mean().item()),
                             "status_histogram": {pkg.capi.TERM_NAMES[int(c)]: int((st == c).sum()) for c in np.unique(st)},
                             "note": "cold start, max_iterations=%d, relative_exit_tol=1e-5, "
@@ -464,7 +464,7 @@ def variants(torch, pkg, args, tdt, dev, local_rank, x0, B):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / ticks
         err = (sim.get_state()[1] - np.pi / 2).abs()
-        return {"ticks/s (controllers x ticks)": B / dt, "ms_per_tick": dt * 1e3, "ticks": ticks,
+        return {"ticks/s (controllers x ticks)": B / dt, "ms_per_tick": dt * 1e3, "ticks": ticks, "stage_plan_last_tick": opt.stage_plan(),
                 "mean_iterations_last_10_ticks": its,
                 "median_abs_pole_angle_error_after_0.5s": float(err.median().item()),
                 "fraction_within_0.1rad_after_0.5s": float((err < 0.1).float().mean().item())}
