@@ -36,7 +36,7 @@ SYMBOLS = [
     "cpmpc_dynamics_batch", "cpmpc_rk4_batch", "cpmpc_linearize_batch", "cpmpc_sim_step_batch",
     "cpmpc_sim_step_batch_host", "cpmpc_model_state_dim", "cpmpc_model_num_params", "cpmpc_create_model",
     "cpmpc_model", "cpmpc_dynamics_batch_model", "cpmpc_rk4_batch_model", "cpmpc_sim_step_batch_model",
-    "cpmpc_set_pipeline", "cpmpc_get_pipeline", "cpmpc_set_compaction", "cpmpc_get_stage_plan",
+    "cpmpc_set_pipeline", "cpmpc_get_pipeline", "cpmpc_set_compaction", "cpmpc_get_stage_plan", "cpmpc_plan_stages_from_histogram",
     "cpmpc_profile_enable", "cpmpc_profile_reset", "cpmpc_profile_read", "cpmpc_kernel_name",
     "cpmpc_sharded_create", "cpmpc_sharded_destroy", "cpmpc_sharded_num_shards", "cpmpc_sharded_device",
     "cpmpc_sharded_handle", "cpmpc_sharded_range", "cpmpc_sharded_reset", "cpmpc_sharded_step_batch_host",
@@ -233,6 +233,7 @@ def load():
     L.cpmpc_get_pipeline.argtypes = [vp]
     L.cpmpc_set_compaction.argtypes = [vp, i32, i32]
     L.cpmpc_get_stage_plan.argtypes = [vp, C.POINTER(C.c_int32), i32]
+    L.cpmpc_plan_stages_from_histogram.argtypes = [C.POINTER(C.c_int64), i64, i32, i32, i32, i32, C.POINTER(C.c_int32), i32]
     L.cpmpc_profile_enable.argtypes = [vp, i32]
     L.cpmpc_profile_reset.argtypes = [vp]
     L.cpmpc_profile_read.argtypes = [vp, i32, _dp, C.POINTER(C.c_int64)]

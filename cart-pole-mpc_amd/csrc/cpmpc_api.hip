@@ -462,6 +462,79 @@ extern "C" int cpmpc_set_compaction(cpmpc_solver* s, int first_iterations, int n
 //    where they do: in a settled closed loop (everybody stops after the first iteration) that is a second, empty launch
 //    per tick (7 us), and it is what keeps a tick in which some controllers are disturbed from being bound by waves
 //    that one disturbed problem in sixteen keeps alive.  Before the first histogram: 2 iterations, then 1 at a time.
+// the plan from a histogram (hist[b] = problems that ran b iterations, the last bin collecting every larger count):
+// bounds[0] = 0 < ... < bounds[n] = T, returns n.  resident = waves of the fused kernel the machine holds (1 / 2 per SIMD)
+static int plan_from_histogram(const double* hist, double n_hist, int64_t B, int T, int ppw, double resident, int window,
+                               int* bounds) {
+  // surv[j]: expected problems of THIS batch needing more than j iterations, j = 0 .. T
+  double surv[kMaxStages + 1];
+  const double scale = (double)B / n_hist;
+  for (int j = 0; j <= T; ++j) {
+    double above = 0.0;
+    for (int b = j + 1; b < kFbBins; ++b) above += hist[b];
+    surv[j] = j < T ? above * scale : 0.0;
+  }
+  surv[0] = (double)B;
+  const double launch = 0.14 * 40.0 / (double)window;        // 7 us in units of one wave-iteration (50 us at N = 40)
+  const double run_out = 2048.0 * (double)ppw;                // the kernel's run_out_below
+  double best[kMaxStages + 2];
+  int next_cut[kMaxStages + 2];
+  best[T] = 0.0;
+  for (int a = T - 1; a >= 0; --a) {
+    best[a] = 1e300;
+    next_cut[a] = T;
+    // a stage that starts at a, by the iteration b it ends at (ascending, the sums carried along)
+    double wave_iters = 0.0, longest = 0.0;
+    for (int b = a + 1; b <= T; ++b) {
+      const int j = b - 1 - a;
+      const double q = surv[a] > 0.0 ? surv[a + j] / surv[a] : 0.0;
+      wave_iters += 1.0 - std::pow(1.0 - (q > 1.0 ? 1.0 : q), (double)ppw);
+      if (surv[a + j] >= 1.0) longest = (double)(j + 1);
+      if (a > 0 && surv[a] <= run_out && b != T) continue;   // such a stage runs to the end by itself
+      const double thr = wave_iters * surv[a] / (double)ppw / resident;
+      const double cost = (thr > longest ? thr : longest) + launch + (b < T ? best[b] : 0.0);
+      if (cost < best[a] - 1e-12 || (b == T && cost <= best[a] + 1e-12)) {   // ties: the fewer launches
+        best[a] = cost;
+        next_cut[a] = b;
+      }
+    }
+  }
+  int n = 0;
+  bounds[0] = 0;
+  for (int a = 0; a < T && n < kMaxStages; a = next_cut[a]) bounds[++n] = next_cut[a];
+  bounds[n] = T;
+  if (n == 1) {  // the insurance cut (see above)
+    for (int j = 1; j < T; ++j)
+      if (surv[j] <= 0.001 * (double)B) {
+        bounds[1] = j;
+        bounds[2] = T;
+        n = 2;
+        break;
+      }
+  }
+  return n;
+}
+
+// the planner alone, for tests and tools (no device, no handle): hist[16] as finalize_kernel reports it
+extern "C" int cpmpc_plan_stages_from_histogram(const int64_t* hist, int64_t B, int max_iterations, int intervals, int dtype,
+                                                int window_length, int32_t* bounds, int capacity) {
+  if (!hist || !bounds || B < 1 || max_iterations < 1 || max_iterations > kMaxStages || intervals < 1 || intervals > 64 ||
+      window_length < 1 || capacity < max_iterations + 1 || (dtype != CPMPC_F32 && dtype != CPMPC_F64))
+    return -1;
+  double h[kFbBins], n_hist = 0.0;
+  for (int b = 0; b < kFbBins; ++b) {
+    if (hist[b] < 0) return -1;
+    h[b] = (double)hist[b];
+    n_hist += h[b];
+  }
+  if (n_hist <= 0.0) return -1;
+  int bnd[kMaxStages + 1];
+  const int n = plan_from_histogram(h, n_hist, B, max_iterations, 64 / intervals, dtype == CPMPC_F64 ? 1024.0 : 2048.0,
+                                    window_length, bnd);
+  for (int i = 0; i <= n; ++i) bounds[i] = bnd[i];
+  return n;
+}
+
 int cpmpc_plan_stages(cpmpc_solver* s, int slot, int64_t B, bool exits, int* bounds) {
   const int T = (int)s->params.max_iterations;
   const int L = s->S - 1, ppw = 64 / L;
@@ -505,53 +578,18 @@ int cpmpc_plan_stages(cpmpc_solver* s, int slot, int64_t B, bool exits, int* bou
     }
   }
   if (seq == 0 || n_hist <= 0.0) return fixed(s->stage_first, s->stage_next);  // nothing to plan from yet
-  // surv[j]: expected problems of THIS batch needing more than j iterations, j = 0 .. T
-  double surv[kMaxStages + 1];
-  const double scale = (double)B / n_hist;
-  for (int j = 0; j <= T; ++j) {
-    double above = 0.0;
-    for (int b = j + 1; b < kFbBins; ++b) above += hist[b];
-    surv[j] = j < T ? above * scale : 0.0;
+  // the same histogram and batch as the last plan made on this slot: the same plan
+  PlanCache& pc = s->plan_cache[slot];
+  if (pc.seq == seq && pc.B == B && pc.n_hist == n_hist && pc.n > 0) {
+    for (int i = 0; i <= pc.n; ++i) bounds[i] = pc.bounds[i];
+    return finish(pc.n);
   }
-  surv[0] = (double)B;
-  const double resident = s->esize == 8 ? 1024.0 : 2048.0;   // waves of the fused kernel the machine holds (1 / 2 per SIMD)
-  const double launch = 0.14 * 40.0 / (double)s->N;           // 7 us in units of one wave-iteration (50 us at N = 40)
-  const double run_out = 2048.0 * (double)ppw;                // the kernel's run_out_below
-  double best[kMaxStages + 2];
-  int next_cut[kMaxStages + 2];
-  best[T] = 0.0;
-  for (int a = T - 1; a >= 0; --a) {
-    best[a] = 1e300;
-    next_cut[a] = T;
-    for (int b = T; b > a; --b) {
-      if (a > 0 && surv[a] <= run_out && b != T) continue;   // such a stage runs to the end by itself
-      double wave_iters = 0.0, longest = 0.0;
-      for (int j = 0; a + j < b; ++j) {
-        const double q = surv[a] > 0.0 ? surv[a + j] / surv[a] : 0.0;
-        wave_iters += 1.0 - std::pow(1.0 - (q > 1.0 ? 1.0 : q), (double)ppw);
-        if (surv[a + j] >= 1.0) longest = (double)(j + 1);
-      }
-      wave_iters *= surv[a] / (double)ppw;
-      const double thr = wave_iters / resident;
-      const double cost = (thr > longest ? thr : longest) + launch + (b < T ? best[b] : 0.0);
-      if (cost < best[a] - 1e-12) {
-        best[a] = cost;
-        next_cut[a] = b;
-      }
-    }
-  }
-  int n = 0;
-  for (int a = 0; a < T && n < kMaxStages; a = next_cut[a]) bounds[++n] = next_cut[a];
-  bounds[n] = T;
-  if (n == 1) {  // the insurance cut (see above)
-    for (int j = 1; j < T; ++j)
-      if (surv[j] <= 0.001 * (double)B) {
-        bounds[1] = j;
-        bounds[2] = T;
-        n = 2;
-        break;
-      }
-  }
+  const int n = plan_from_histogram(hist, n_hist, B, T, ppw, s->esize == 8 ? 1024.0 : 2048.0, s->N, bounds);
+  pc.seq = seq;
+  pc.B = B;
+  pc.n_hist = n_hist;
+  pc.n = n;
+  for (int i = 0; i <= n; ++i) pc.bounds[i] = bounds[i];
   return finish(n);
 }
 

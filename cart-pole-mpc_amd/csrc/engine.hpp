@@ -51,6 +51,15 @@ struct HostSlot {
   bool per_dyn = false, per_sp = false, per_tw = false;  // which per-problem inputs the chunk carried (staging layout)
 };
 
+// the last plan made from a histogram, per host slot (cpmpc_plan_stages)
+struct PlanCache {
+  int seq = 0;
+  int64_t B = 0;
+  double n_hist = 0.0;
+  int n = 0;
+  int bounds[kMaxStages + 1] = {0};
+};
+
 struct cpmpc_solver {
   cpmpc_params params;
   cpmpc_solver_opts opts;
@@ -96,6 +105,7 @@ struct cpmpc_solver {
   int fb_reporters[kHostSlots] = {0, 0, 0};  // reporting workgroups of the last step launched on the slot
   int last_plan[kMaxStages + 1] = {0};  // boundaries of the stages of the last step (cpmpc_get_stage_plan)
   int last_plan_n = 0;
+  PlanCache plan_cache[kHostSlots];
 };
 
 

@@ -430,6 +430,11 @@ int cpmpc_set_compaction(cpmpc_solver* s, int first_iterations, int next_iterati
  * This reads back the plan of the last step: bounds[0] = 0 < ... < bounds[n] = max_iterations, returns n (the number of
  * launches of the fused kernel), -1 on a bad argument. */
 int cpmpc_get_stage_plan(const cpmpc_solver* s, int32_t* bounds, int capacity);
+/* The planner alone (no device, no handle; for tests and tools): hist[16], hist[k] = problems that ran k iterations (the
+ * last bin collects every larger count), for a batch of B problems with `intervals` = S - 1 shooting intervals.  Writes
+ * bounds[0 .. n], returns n; -1 on a bad argument (max_iterations must be 1 .. 16, capacity >= max_iterations + 1). */
+int cpmpc_plan_stages_from_histogram(const int64_t* hist, int64_t B, int max_iterations, int intervals, int dtype,
+                                     int window_length, int32_t* bounds, int capacity);
 int cpmpc_get_pipeline(const cpmpc_solver* s); /* the one a step will actually use: SPLIT or FUSED */
 
 /* When enabled, every kernel launch of cpmpc_step_batch is bracketed by HIP events on the launch

@@ -181,3 +181,96 @@ def test_product_does_not_import_the_oracle():
             if name.endswith((".py", ".hip", ".hpp", ".h", ".cc", ".cpp")):
                 text = open(os.path.join(base, name), errors="replace").read()
                 assert "oracle" not in text.lower().replace("no cpu fallback", ""), os.path.join(base, name)
+
+
+def _plan(lib, hist, B=262144, T=8, intervals=4, dtype=1, window=40):
+    h = (C.c_int64 * 16)(*([int(v) for v in hist] + [0] * (16 - len(hist))))
+    out = (C.c_int32 * 32)()
+    n = lib.cpmpc_plan_stages_from_histogram(h, B, T, intervals, dtype, window, out, 32)
+    assert n >= 1
+    return [int(out[i]) for i in range(n + 1)]
+
+
+def _plan_cost(bounds, hist, B, T, ppw, resident, window):
+    """The cost model of csrc/cpmpc_api.hip: plan_from_histogram, restated: time of a plan in wave-iterations."""
+    tot = float(sum(hist))
+    surv = [B * sum(hist[j + 1:]) / tot if j < T else 0.0 for j in range(T + 1)]
+    surv[0] = float(B)
+    launch, run_out = 0.14 * 40.0 / window, 2048.0 * ppw
+    cost = 0.0
+    for a, b in zip(bounds, bounds[1:]):
+        if a > 0 and surv[a] <= run_out and b != T:
+            return None            # not a plan the kernel would follow: such a stage runs to the end
+        wi, longest = 0.0, 0.0
+        for j in range(b - a):
+            q = min(1.0, surv[a + j] / surv[a]) if surv[a] > 0 else 0.0
+            wi += 1.0 - (1.0 - q) ** ppw
+            if surv[a + j] >= 1.0:
+                longest = j + 1.0
+        cost += max(wi * surv[a] / ppw / resident, longest) + launch
+    return cost
+
+
+def test_stage_planner_known_cases_and_optimality(lib, pkg):
+    """cpmpc_plan_stages_from_histogram (host only): the plans of the workloads measured in DESIGN 6.4, and on random
+    histograms the plan is the cheapest partition of [0, T) under the documented cost model (checked by enumeration)."""
+    import itertools
+    import numpy as np
+    F32, F64 = pkg.capi.F32, pkg.capi.F64
+    B = 262144
+    # settled closed loop: everybody stops after one iteration -> that launch and the insurance cut
+    assert _plan(lib, [0, B], dtype=F64) == [0, 1, 8]
+    assert _plan(lib, [0, 0, B], dtype=F32) == [0, 2, 8]
+    # cold start, nearly everybody runs to the cap: nothing to gain from compaction until late, if at all
+    cold = [0, 3, 53, 60, 476, 1494, 2221, 3053, 254784]
+    p = _plan(lib, cold, dtype=F32)
+    assert p[0] == 0 and p[-1] == 8 and p[1] >= 5
+    # fp32 at the reference's tolerances (profiles/r04_steady_state_f32.json): cuts where the bulk leaves
+    spread = [0, 282, 117494, 93908, 36758, 10807, 2322, 469, 104]
+    assert _plan(lib, spread, dtype=F32) == [0, 2, 3, 8]
+    # everybody at the cap: one launch, no insurance cut (nobody stops early)
+    assert _plan(lib, [0] * 8 + [B], dtype=F64) == [0, 8]
+    # a sample of the batch plans like the whole batch
+    assert _plan(lib, [v // 4 for v in spread], dtype=F32) == [0, 2, 3, 8]
+    # bad arguments
+    out = (C.c_int32 * 32)()
+    h = (C.c_int64 * 16)()
+    assert lib.cpmpc_plan_stages_from_histogram(h, B, 8, 4, F64, 40, out, 32) == -1      # empty histogram
+    h[1] = 5
+    assert lib.cpmpc_plan_stages_from_histogram(h, B, 17, 4, F64, 40, out, 32) == -1     # more stages than kMaxStages
+    assert lib.cpmpc_plan_stages_from_histogram(h, B, 8, 4, F64, 40, out, 4) == -1       # bounds too short
+    rng = np.random.default_rng(3)
+    for case in range(300):
+        T = int(rng.integers(2, 9))
+        intervals = int(rng.choice([2, 4, 5, 8, 10, 16]))
+        dtype = F64 if case % 2 else F32
+        hist = np.zeros(16, dtype=np.int64)
+        kind = case % 3
+        if kind == 0:
+            hist[1:T + 1] = rng.integers(0, 100000, T)
+        elif kind == 1:   # most stop early, a thin tail
+            hist[1] = 250000
+            hist[2:T + 1] = rng.integers(0, 200, T - 1)
+        else:             # most run to the cap
+            hist[T] = 250000
+            hist[1:T] = rng.integers(0, 3000, T - 1)
+        if hist.sum() == 0:
+            hist[1] = 1
+        Bc = int(rng.choice([40000, 262144, 1000000]))
+        got = _plan(lib, hist, B=Bc, T=T, intervals=intervals, dtype=dtype)
+        assert got[0] == 0 and got[-1] == T and all(b > a for a, b in zip(got, got[1:]))
+        ppw, resident = 64 // intervals, (1024.0 if dtype == F64 else 2048.0)
+        best = None
+        for k in range(T):
+            for cuts in itertools.combinations(range(1, T), k):
+                c = _plan_cost([0, *cuts, T], list(hist), Bc, T, ppw, resident, 40)
+                if c is not None and (best is None or c < best - 1e-9):
+                    best = c
+        c_got = _plan_cost(got, list(hist), Bc, T, ppw, resident, 40)
+        if len(got) == 3 and c_got is not None and c_got > best + 1e-9:
+            # the insurance cut: one launch was cheapest, the cut sits where 99.9 % have stopped
+            assert abs(_plan_cost([0, T], list(hist), Bc, T, ppw, resident, 40) - best) < 1e-9, (case, got)
+            tot = hist.sum()
+            assert hist[got[1] + 1:].sum() <= 0.001 * tot + 1e-9 and (got[1] == 1 or hist[got[1]:].sum() > 0.001 * tot)
+        else:
+            assert c_got is not None and c_got <= best + 1e-9, (case, got, c_got, best)
