@@ -447,12 +447,15 @@ def variants(torch, pkg, args, tdt, dev, local_rank, x0, B):
     xs = np.stack([rng.uniform(-0.3, 0.3, B), np.pi / 2 + rng.uniform(-0.4, 0.4, B), rng.uniform(-0.5, 0.5, B),
                    rng.uniform(-1, 1, B)])
 
-    def closed_loop(dt_torch, **over):
+    def closed_loop(dt_torch, settle=0, **over):
         sim = pkg.BatchSimulator(B, dtype=dt_torch, device=local_rank)
         sim.set_state(torch.tensor(xs, dtype=dt_torch, device=dev))
         opt = pkg.BatchOptimization(pkg.default_params(**over), max_batch=B, dtype=dt_torch, device=local_rank)
         opt.set_pipeline(args.pipeline)
         out = pkg.BatchOutputs()   # this loop's own buffers (its dtype)
+        for _ in range(settle):    # untimed: bring the controllers to their set-point first
+            o = opt.step(sim.get_state(), DYN_UI, 0.0, want_predicted=False, want_stats=True, out=out)
+            sim.step(DYN_UI, 0.01, o.u[0].contiguous())
         its = 0.0
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -480,6 +483,14 @@ def variants(torch, pkg, args, tdt, dev, local_rank, x0, B):
         # the closed-loop accuracy (set by fp32 state storage, ~6e-6 rad) is the same (profiles/r04_soak_f32*.json)
         res["closed_loop_warm_start_fo_tol_1e-4"] = closed_loop(tdt, absolute_first_derivative_tol=1e-4)
         res["closed_loop_warm_start_fp64"] = closed_loop(torch.float64)
+    # the same loops once the controllers have settled (300 untimed ticks first): what a tick costs in steady state
+    res["closed_loop_settled"] = {
+        "note": "300 untimed ticks, then 50 timed; reference defaults; the stages of the fused pipeline planned per step "
+                "from the iteration histogram of an earlier step (DESIGN.md 6.4)",
+        "f32" if tdt == torch.float32 else "f64": closed_loop(tdt, settle=300)}
+    if tdt == torch.float32:
+        res["closed_loop_settled"]["f32_fo_tol_1e-4"] = closed_loop(tdt, settle=300, absolute_first_derivative_tol=1e-4)
+        res["closed_loop_settled"]["f64"] = closed_loop(torch.float64, settle=300)
     try:
         res["per_problem_params"] = per_problem_variant(torch, pkg, args, dev, local_rank, B)
     except Exception as exc:  # noqa: BLE001

@@ -461,7 +461,8 @@ extern "C" int cpmpc_set_compaction(cpmpc_solver* s, int first_iterations, int n
 //    a plan that comes out as ONE launch although the histogram says nearly everybody (99.9 %) stops early gets one cut
 //    where they do: in a settled closed loop (everybody stops after the first iteration) that is a second, empty launch
 //    per tick (7 us), and it is what keeps a tick in which some controllers are disturbed from being bound by waves
-//    that one disturbed problem in sixteen keeps alive.  Before the first histogram: 2 iterations, then 1 at a time.
+//    that one disturbed problem in sixteen keeps alive.  Before the first histogram, and when the only histogram there is
+//    is old and the counts are moving (see below): 2 iterations, then 1 at a time.
 // the plan from a histogram (hist[b] = problems that ran b iterations, the last bin collecting every larger count):
 // bounds[0] = 0 < ... < bounds[n] = T, returns n.  resident = waves of the fused kernel the machine holds (1 / 2 per SIMD)
 static int plan_from_histogram(const double* hist, double n_hist, int64_t B, int T, int ppw, double resident, int window,
@@ -578,8 +579,26 @@ int cpmpc_plan_stages(cpmpc_solver* s, int slot, int64_t B, bool exits, int* bou
     }
   }
   if (seq == 0 || n_hist <= 0.0) return fixed(s->stage_first, s->stage_next);  // nothing to plan from yet
-  // the same histogram and batch as the last plan made on this slot: the same plan
+  // How old may the histogram be?  A caller that synchronises every tick (a controller acting on u) plans from the tick
+  // before.  One that queues ticks ahead plans from whatever has finished, many ticks back: right while the iteration
+  // counts hold still, wrong in a transient (a swing-up queued ahead ran 2.0 -> 2.7 ms per tick on plans made for ticks
+  // long gone).  So: a histogram at most two steps old is used as it is; an older one only if it agrees with the one seen
+  // before it (no bin's share moved by more than 2 % of the batch); otherwise the fixed pattern.
   PlanCache& pc = s->plan_cache[slot];
+  if (pc.seen_seq != seq) {
+    double moved = 0.0;
+    for (int b = 0; b < kFbBins; ++b) {
+      const double share = hist[b] / n_hist, d = share - pc.seen[b];
+      moved = (d < 0.0 ? -d : d) > moved ? (d < 0.0 ? -d : d) : moved;
+      pc.seen[b] = share;
+    }
+    pc.stationary = pc.have_prev && moved <= 0.02;
+    pc.have_prev = true;
+    pc.seen_seq = seq;
+  }
+  const bool fresh = s->fb_seq[slot] - seq <= 2;
+  if (!fresh && !pc.stationary) return fixed(s->stage_first, s->stage_next);
+  // the same histogram and batch as the last plan made on this slot: the same plan
   if (pc.seq == seq && pc.B == B && pc.n_hist == n_hist && pc.n > 0) {
     for (int i = 0; i <= pc.n; ++i) bounds[i] = pc.bounds[i];
     return finish(pc.n);

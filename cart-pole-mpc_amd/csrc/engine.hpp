@@ -58,6 +58,10 @@ struct PlanCache {
   double n_hist = 0.0;
   int n = 0;
   int bounds[kMaxStages + 1] = {0};
+  // the last two different histograms the host has seen on the slot, as fractions of problems per bin
+  int seen_seq = 0;
+  double seen[kFbBins] = {0};
+  bool have_prev = false, stationary = false;
 };
 
 struct cpmpc_solver {

@@ -361,9 +361,12 @@ def test_opts_size_versions_the_solver_options(pkg):
 # ------------------------------------------------------------------------------------------------
 # e: the sharded boundary, device-resident form
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("layout", ["three_shards_on_one_gpu", "one_shard_per_gpu"])
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
-def test_sharded_device_step_takes_per_problem_inputs_and_returns_the_solution(pkg, dtype):
-    """cpmpc_sharded_step_batch_ex: every array of cpmpc_step_inputs (x0, per-problem dyn / set-point / terminal rows)
+def test_sharded_device_step_takes_per_problem_inputs_and_returns_the_solution(pkg, dtype, layout):
+    """(`one_shard_per_gpu` runs where the box has at least two GPUs -- the root-device `ready` event, the peer copies and
+    the per-device guards are only real there -- and is skipped otherwise.)
+    cpmpc_sharded_step_batch_ex: every array of cpmpc_step_inputs (x0, per-problem dyn / set-point / terminal rows)
     and every output incl. the solution z, the guess and the merit-evaluation counts on the root device; three shards on
     device 0, ragged B.  Bitwise the single handle.  Then the warm start: cpmpc_sharded_get_solution == the single
     handle's, a step with ANOTHER batch size hands it over instead of misaligning it, and
@@ -379,6 +382,13 @@ def test_sharded_device_step_takes_per_problem_inputs_and_returns_the_solution(p
                       np.where(np.arange(B) % 5 == 0, 5.0, -1.0)])
     params = pkg.default_params(**NO_TOL)
     stream = torch.cuda.current_stream().cuda_stream
+    if layout == "one_shard_per_gpu":
+        n_gpus = lib.cpmpc_device_count()
+        if n_gpus < 2:
+            pytest.skip("needs at least two GPUs (this box has %d)" % n_gpus)
+        shard_devices = list(range(min(n_gpus, 8)))
+    else:
+        shard_devices = [0, 0, 0]
 
     def outputs(nb, dim):
         t = dict(u=torch.full((N, nb), float("nan"), dtype=dtype, device=DEV),
@@ -409,8 +419,8 @@ def test_sharded_device_step_takes_per_problem_inputs_and_returns_the_solution(p
     single = C.c_void_p()
     pkg.capi.check(lib.cpmpc_create(C.byref(params), None, cdt, B, 0, C.byref(single)))
     sharded = C.c_void_p()
-    devs = (C.c_int * 3)(0, 0, 0)
-    pkg.capi.check(lib.cpmpc_sharded_create(C.byref(params), None, cdt, B, devs, 3, C.byref(sharded)))
+    devs = (C.c_int * len(shard_devices))(*shard_devices)
+    pkg.capi.check(lib.cpmpc_sharded_create(C.byref(params), None, cdt, B, devs, len(shard_devices), C.byref(sharded)))
     dim = lib.cpmpc_dim(single)
     try:
         # per-problem inputs, then shared ones warm-started from them; then other batch sizes (growing, shrinking)
