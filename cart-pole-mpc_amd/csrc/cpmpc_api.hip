@@ -596,7 +596,8 @@ int cpmpc_plan_stages(cpmpc_solver* s, int slot, int64_t B, bool exits, int* bou
     pc.have_prev = true;
     pc.seen_seq = seq;
   }
-  const bool fresh = s->fb_seq[slot] - seq <= 2;
+  const int age = s->fb_seq[slot] >= seq ? s->fb_seq[slot] - seq : s->fb_seq[slot] + (1 << 30) - seq;  // steps launched since
+  const bool fresh = age <= 2;
   if (!fresh && !pc.stationary) return fixed(s->stage_first, s->stage_next);
   // the same histogram and batch as the last plan made on this slot: the same plan
   if (pc.seq == seq && pc.B == B && pc.n_hist == n_hist && pc.n > 0) {

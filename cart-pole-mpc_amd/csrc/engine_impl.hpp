@@ -273,7 +273,9 @@ static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* 
     const int64_t groups = (B + CPMPC_PF_BLOCK - 1) / CPMPC_PF_BLOCK;
     a.fb_stride = (int)((groups + kFbReporters - 1) / kFbReporters);
     a.fb_host = s->fb_host_dev + (size_t)slot * kFbReporters * (kFbBins + 1);
-    a.fb_seq = ++s->fb_seq[slot];
+    // sequence numbers 1 .. 2^30 and round again (0 = "no report yet"); compared modulo 2^30 in cpmpc_plan_stages
+    s->fb_seq[slot] = s->fb_seq[slot] >= (1 << 30) ? 1 : s->fb_seq[slot] + 1;
+    a.fb_seq = s->fb_seq[slot];
     s->fb_reporters[slot] = (int)((groups + a.fb_stride - 1) / a.fb_stride);
   }
   span_begin(s, CPMPC_KERNEL_FINALIZE, stream, &sp);
