@@ -121,6 +121,15 @@ def condensed(Phi, Gam, cs, ci, e_term, Rw, Dg, u, u_prev, wu, wd, dt, hi=()):
             t[j] = (hvd[j] - R[:j, j] @ t[:j]) / R[j, j]
         z = t - Qt.T @ ct
         y = (-(sd * (ct + Qt @ z))).astype(dt)
+        if 'sn' in hi:   # semi-normal equations: q = R^-1 R^-T (hv - rho), y = -(gw + W q), with only R from the QR
+            rhs = (hv - rho).astype(dt)
+            t2 = np.zeros(4, dt)
+            for j in range(4):
+                t2[j] = (rhs[j] - R[:j, j] @ t2[:j]) / R[j, j]
+            q = np.zeros(4, dt)
+            for j in range(3, -1, -1):
+                q[j] = (t2[j] - R[j, j + 1:] @ q[j + 1:]) / R[j, j]
+            y = (-(gw + W.astype(dt) @ q)).astype(dt)
     else:
         q = lu_solve(Sm, (hv - rho).astype(tS), tS)
         ty = HI if 'y' in hi else dt
@@ -207,7 +216,7 @@ rng = np.random.default_rng(500 + 14)
 x0s = np.stack([rng.uniform(-0.6, 0.6, B), rng.uniform(-np.pi, np.pi, B), rng.uniform(-1, 1, B), rng.uniform(-3, 3, B)])
 x0s[1, ::2] = np.pi / 2 + rng.uniform(-0.5, 0.5, x0s[1, ::2].shape)
 variants = [("dense KKT f64", None), ("riccati f64", 'ric'), ("condensed f64", ()), ("S", ('S',)), ("S,rho", ('S', 'rho')), ("S,rho,y", ('S','rho','y')),
-            ("qr (householder)", ('qr',)), ("qr (givens rows)", ('qr', 'givens')), ("qr + psi hi", ('qr', 'psi')), ("rho,y", ('rho', 'y')), ("S,y", ('S', 'y')), ("S,rho,y,psi", ('S','rho','y','psi')), ("all", ('S','rho','y','psi','rec'))]
+            ("qr (householder)", ('qr',)), ("qr (givens rows)", ('qr', 'givens')), ("qr semi-normal", ('qr', 'givens', 'sn')), ("qr + psi hi", ('qr', 'psi')), ("rho,y", ('rho', 'y')), ("S,y", ('S', 'y')), ("S,rho,y,psi", ('S','rho','y','psi')), ("all", ('S','rho','y','psi','rec'))]
 import os
 if os.environ.get("VARIANTS"):
     keep = os.environ["VARIANTS"].split(";")
