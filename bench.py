@@ -484,13 +484,16 @@ def variants(torch, pkg, args, tdt, dev, local_rank, x0, B):
         res["closed_loop_warm_start_fo_tol_1e-4"] = closed_loop(tdt, absolute_first_derivative_tol=1e-4)
         res["closed_loop_warm_start_fp64"] = closed_loop(torch.float64)
     # the same loops once the controllers have settled (300 untimed ticks first): what a tick costs in steady state
-    res["closed_loop_settled"] = {
-        "note": "300 untimed ticks, then 50 timed; reference defaults; the stages of the fused pipeline planned per step "
-                "from the iteration histogram of an earlier step (DESIGN.md 6.4)",
-        "f32" if tdt == torch.float32 else "f64": closed_loop(tdt, settle=300)}
-    if tdt == torch.float32:
-        res["closed_loop_settled"]["f32_fo_tol_1e-4"] = closed_loop(tdt, settle=300, absolute_first_derivative_tol=1e-4)
-        res["closed_loop_settled"]["f64"] = closed_loop(torch.float64, settle=300)
+    try:
+        res["closed_loop_settled"] = {
+            "note": "300 untimed ticks, then 50 timed; reference defaults; the stages of the fused pipeline planned per step "
+                    "from the iteration histogram of an earlier step (DESIGN.md 6.4)",
+            "f32" if tdt == torch.float32 else "f64": closed_loop(tdt, settle=300)}
+        if tdt == torch.float32:
+            res["closed_loop_settled"]["f32_fo_tol_1e-4"] = closed_loop(tdt, settle=300, absolute_first_derivative_tol=1e-4)
+            res["closed_loop_settled"]["f64"] = closed_loop(torch.float64, settle=300)
+    except Exception as exc:  # noqa: BLE001
+        res["closed_loop_settled"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     try:
         res["per_problem_params"] = per_problem_variant(torch, pkg, args, dev, local_rank, B)
     except Exception as exc:  # noqa: BLE001
