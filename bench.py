@@ -477,10 +477,10 @@ def variants(torch, pkg, args, tdt, dev, local_rank, x0, B):
                                              "shifted previous solution, plant = 10 RK4 sub-steps per tick, states "
                                              "start within 0.4 rad of upright")
     if tdt == torch.float32:
-        # Single precision cannot resolve the reference's absolute_first_derivative_tol = 1e-6: the merit slope carries
-        # mu x |c|_1 ~ 3e-6 of rounding of the fp32 node states, so converged controllers never take the first-order
-        # exit and keep iterating (2.8 iterations per tick where fp64 needs 1.0).  With the tolerance at 1e-4 they do;
-        # the closed-loop accuracy (set by fp32 state storage, ~6e-6 rad) is the same (profiles/r04_soak_f32*.json)
+        # Single precision cannot resolve the reference's absolute_first_derivative_tol = 1e-6 on its own: the merit
+        # slope carries mu x |c|_1 of the rounding of the fp32 rollout.  Since round 4 the exit test counts residuals at
+        # that floor as zero (cpmpc_solver_opts.exit_defect_floor): 1.8 iterations per settled tick instead of 2.8 (fp64:
+        # 1.0).  With the tolerance at 1e-4 it is 1.0; the closed-loop accuracy (fp32 state storage, ~6e-6 rad) is the same
         res["closed_loop_warm_start_fo_tol_1e-4"] = closed_loop(tdt, absolute_first_derivative_tol=1e-4)
         res["closed_loop_warm_start_fp64"] = closed_loop(torch.float64)
     # the same loops once the controllers have settled (300 untimed ticks first): what a tick costs in steady state

@@ -85,6 +85,7 @@ class SolverOpts(C.Structure):
         ("u_limit", C.c_double),
         ("ls_alpha_growth_backtracked", C.c_double),
         ("full_step_below", C.c_double),
+        ("exit_defect_floor", C.c_double),
     ]
 
 

@@ -74,6 +74,7 @@ extern "C" void cpmpc_default_solver_opts(cpmpc_solver_opts* o) {
   o->u_limit = 300.0;  // optimization.cc:327
   o->ls_alpha_growth_backtracked = 2.0;
   o->full_step_below = 1.0e-4;
+  o->exit_defect_floor = 2.0;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -4,6 +4,7 @@
 #pragma once
 #include <cmath>
 #include <cstring>
+#include <limits>
 
 #include "engine.hpp"
 #include "mpc_kernels.hpp"
@@ -61,6 +62,7 @@ static void fill_args(const cpmpc_solver* s, int64_t B, SolverArgs<R, M>& a, int
   a.alpha_growth = (R)o.ls_alpha_growth;
   a.alpha_growth_bt = (R)o.ls_alpha_growth_backtracked;
   a.full_step_below = (R)o.full_step_below;
+  a.cn_floor_scale = (R)(o.exit_defect_floor * (double)s->SP * (double)std::numeric_limits<R>::epsilon());
   a.rho = (R)o.penalty_rho;
   a.lam_init = (R)o.lambda_initial;
   a.lam_fail_init = (R)o.lambda_failure_init;

@@ -123,6 +123,7 @@ struct SolverArgs {
   // solver options
   int max_ls;
   R c1, shrink_max, shrink_min, alpha_growth, alpha_growth_bt, rho, full_step_below;
+  R cn_floor_scale;  // exit_defect_floor * state_spacing * eps(R): |c|_1 up to this times sum |x_s| is rounding (first-order exit test)
   R lam_init, lam_fail_init, lam_up, lam_down, lam_min, lam_max;
   R bx_lim, u_lim;
   R rel_tol, fo_tol, mu_init;
@@ -1110,7 +1111,16 @@ __global__ CPMPC_QPLS_BOUNDS void qp_ls_kernel(const SolverArgs<R, M> a) {
   }
   const R D = gd - mu * cn;
   const R phi0 = f + mu * cn;
-  const bool first_order = Math<R>::fabs(D) < a.fo_tol;
+  // equality residuals at the rounding floor of the rollout count as zero in the exit test
+  R x_l1 = R(0);
+  for (int s = 1; s < S; ++s) {
+    R xv[NX];
+    unpack<R, NX>(a.zx[(int64_t)s * st + p], xv);
+#pragma unroll
+    for (int t = 0; t < NX; ++t) x_l1 += Math<R>::fabs(xv[t]);
+  }
+  const R D_exit = gd - mu * (cn > a.cn_floor_scale * x_l1 ? cn : R(0));
+  const bool first_order = Math<R>::fabs(D_exit) < a.fo_tol;
 
   // ---- Armijo line search, lock-step over the wave ----------------------------------------------
   // Local convergence safeguard: a QP step that is tiny in every component is taken in full

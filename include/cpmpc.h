@@ -97,6 +97,13 @@ typedef struct cpmpc_solver_opts {
   double ls_alpha_growth_backtracked; /* growth used instead of ls_alpha_growth when the accepted search backtracked */
   double full_step_below; /* an UNDAMPED QP step (lambda = 0) with |dz|_inf <= this is taken in full without the merit
                            * test (local convergence safeguard; default 1e-4, 0 disables) */
+  double exit_defect_floor; /* the first-order exit test |g.dz - mu |c|_1| < absolute_first_derivative_tol counts |c|_1 as
+                             * zero when it is at most exit_defect_floor * state_spacing * eps * sum |x_s| over the shooting
+                             * nodes (eps of the kernels' arithmetic): equality residuals of that size are the rounding of
+                             * the rollout itself -- state_spacing RK4 steps -- and no iteration can remove them.  In fp64
+                             * that floor is 3e-14 and changes nothing; in fp32 it is 1.5e-5, and it is what lets settled
+                             * controllers leave after one iteration at the reference's tolerance of 1e-6 instead of
+                             * iterating on noise (DESIGN.md sections 4 and 6.4; default 2, 0 disables; appended in round 4) */
 } cpmpc_solver_opts;
 
 void cpmpc_default_params(cpmpc_params* p);           /* optimization.hpp:12-48 defaults */

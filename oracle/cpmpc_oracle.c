@@ -10,11 +10,17 @@
  */
 #include "cpmpc_oracle.h"
 
+#include <float.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
+#endif
+
+/* machine epsilon of the arithmetic this file is compiled in (cpmpc_oracle_ld.c sets the long double one) */
+#ifndef ORC_EPS
+#define ORC_EPS DBL_EPSILON
 #endif
 
 #ifndef M_PI
@@ -62,6 +68,7 @@ void orc_default_solver_opts(orc_solver_opts* o) {
   o->u_limit = 300.0;
   o->ls_alpha_growth_backtracked = 2.0;
   o->full_step_below = 1.0e-4;
+  o->exit_defect_floor = 2.0;
 }
 
 /* ------------------------------------------------------------------------------------------- */
@@ -878,8 +885,16 @@ static int solve(const orc_model* m, const orc_opt_params* p, const orc_solver_o
     }
     const double D = gd - mu * cn;
     const double phi0 = f + mu * cn;
-    /* first-order test: the step is still tried (and kept if it passes Armijo) before exiting */
-    const int first_order = fabs(D) < p->absolute_first_derivative_tol;
+    /* first-order test: the step is still tried (and kept if it passes Armijo) before exiting.  Equality residuals at
+     * the rounding floor of their own evaluation -- the shooting defects are differences of states after state_spacing
+     * RK4 steps -- count as zero here: no iteration can remove them, and in single precision mu |c|_1 at that floor
+     * (1e-6 .. 1e-4) would keep a converged controller iterating on noise for ever (round 4; in double the floor is
+     * 3e-14 and changes nothing).  The merit and the Armijo test use the residuals as they are. */
+    double x_l1 = 0.0;
+    for (int j = m->nx; j < m->nx * num_states(p); ++j) x_l1 += fabs(z[j]);
+    const double cn_floor = o->exit_defect_floor * (double)p->state_spacing * (double)ORC_EPS * x_l1;
+    const double D_exit = gd - mu * (cn > cn_floor ? cn : 0.0);
+    const int first_order = fabs(D_exit) < p->absolute_first_derivative_tol;
 
     /* Armijo backtracking along the retraction; the next trial step is the minimiser of the
      * quadratic through phi(0), phi'(0), phi(alpha), safeguarded to [ls_shrink_min, ls_shrink_max]

@@ -76,6 +76,8 @@ typedef struct orc_solver_opts {
   double u_limit;                     /* 300.0 (optimization.cc:327) */
   double ls_alpha_growth_backtracked; /* growth used instead of ls_alpha_growth when the accepted search had to backtrack */
   double full_step_below; /* a QP step with |dz|_inf <= this is taken in full without the merit test (0 disables) */
+  double exit_defect_floor; /* the first-order exit test counts |c|_1 as zero up to this x state_spacing x eps x sum |x_s|
+                             * over the shooting nodes: the rounding of the rollout (default 2, 0 disables) */
 } orc_solver_opts;
 
 /* Termination states; names follow mini_opt::NLSTerminationState as used by the reference

@@ -11,6 +11,7 @@
  * The public structs (orc_opt_params, orc_solver_opts, orc_solver_summary) keep their double fields; the functions
  * are renamed orcld_* and take long double arrays; orcld_step_batch_cold_d below is the double-typed entry point the
  * tests call. */
+#include <float.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -58,6 +59,7 @@
 #define orc_optimization orcld_optimization
 typedef struct orcld_optimization orcld_optimization;
 
+#define ORC_EPS LDBL_EPSILON
 #define double long double
 #define sin sinl
 #define cos cosl

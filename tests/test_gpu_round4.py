@@ -221,6 +221,40 @@ def test_stage_plan_follows_the_iteration_histogram_and_changes_no_result(pkg, d
         assert uniform[-1] == 1 and checked > 5              # settled: SATISFIED_FIRST_ORDER_TOL after one iteration
 
 
+def test_fp32_settled_controllers_do_not_iterate_on_rounding(pkg):
+    """cpmpc_solver_opts.exit_defect_floor (round 4): in the first-order exit test equality residuals at the rounding floor
+    of the rollout count as zero.  Single precision, the reference's tolerances (absolute_first_derivative_tol = 1e-6),
+    controllers settled at the set-point: with the floor (default) most leave after one iteration, without it (0) none can
+    -- mu |c|_1 of the rounding alone is 1e-6 .. 1e-4 -- and they iterate until the relative test happens to pass.  The
+    poles stand equally well either way, and in double precision the floor changes nothing at all (bit for bit)."""
+    B, ticks = 8192, 260
+    rng = np.random.default_rng(23)
+    xs = np.stack([rng.uniform(-0.05, 0.05, B), np.pi / 2 + rng.uniform(-0.05, 0.05, B), rng.uniform(-0.1, 0.1, B), rng.uniform(-0.1, 0.1, B)])
+
+    def run(dtype, floor):
+        sim = pkg.BatchSimulator(B, dtype=dtype, device=0)
+        sim.set_state(T(xs, dtype))
+        opt = pkg.BatchOptimization(pkg.default_params(), max_batch=B, dtype=dtype, device=0,
+                                    opts=pkg.capi.default_solver_opts(exit_defect_floor=floor))
+        out = pkg.BatchOutputs()
+        its = []
+        for k in range(ticks):
+            o = opt.step(sim.get_state(), DYN_UI, 0.0, want_predicted=False, want_stats=True, out=out)
+            sim.step(DYN_UI, 0.01, o.u[0])
+            if k >= ticks - 20:
+                its.append(float(o.iterations.float().mean().item()))
+        err = (sim.get_state()[1].double() - np.pi / 2).abs().max().item()
+        return float(np.mean(its)), err, sim.get_state().clone(), o.u.clone()
+
+    with_floor, err_a, _, _ = run(torch.float32, 2.0)
+    without, err_b, _, _ = run(torch.float32, 0.0)
+    assert with_floor < 2.0 < 2.4 < without, (with_floor, without)
+    assert err_a < 2e-5 and err_b < 2e-5, (err_a, err_b)
+    _, _, s_a, u_a = run(torch.float64, 2.0)
+    _, _, s_b, u_b = run(torch.float64, 0.0)
+    assert torch.equal(s_a, s_b) and torch.equal(u_a, u_b)
+
+
 def test_out_buffers_of_the_other_precision_are_replaced_not_written_through(pkg):
     """BatchOptimization.step(out=...) reuses the caller's output tensors only if shape, dtype and device all match: a
     BatchOutputs filled by an fp32 optimizer handed to an fp64 one has the right SHAPES and half the bytes (an fp64 kernel
