@@ -103,7 +103,9 @@ typedef struct cpmpc_solver_opts {
                              * the rollout itself -- state_spacing RK4 steps -- and no iteration can remove them.  In fp64
                              * that floor is 3e-14 and changes nothing; in fp32 it is 1.5e-5, and it is what lets settled
                              * controllers leave after one iteration at the reference's tolerance of 1e-6 instead of
-                             * iterating on noise (DESIGN.md sections 4 and 6.4; default 2, 0 disables; appended in round 4) */
+                             * iterating on noise (DESIGN.md sections 4 and 6.4; default 2, 0 disables; appended in round 4).
+                             * Measured, fp32, 65 536 settled controllers: 0 -> 2.8 iterations per tick, 2 -> 1.8, 8 -> 1.0,
+                             * the same closed-loop accuracy throughout */
 } cpmpc_solver_opts;
 
 void cpmpc_default_params(cpmpc_params* p);           /* optimization.hpp:12-48 defaults */
