@@ -18,6 +18,13 @@ SOURCES = [os.path.join(CSRC, u + ".hip") for u in UNITS]
 # SLP vectoriser's packing plus its pairing moves is a net loss here (measured 91M -> 104M re-plans/s, 255 -> 189 VGPRs
 # for the fused SQP kernel)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC"]
+# per unit.  The float kernels are scheduled by LLVM's iterative ILP strategy: at two waves per SIMD they wait on their own
+# dependent chains (SQ_WAIT_INST_ANY 30 % of wave-cycles) and that scheduler spaces them better -- same instructions, same
+# results, 117.1 -> 119.8 M re-plans/s in two same-session A/Bs (round 4, tools/ab_both.sh; no spills instead of 4).  The
+# double kernels (one wave per SIMD, at the register limit) lose 0.4 % with it and 1.5 - 4 % with max-ilp, iterative-minreg,
+# iterative-maxocc and max-memory-clause, so they keep the default; amdgpu-schedule-metric-bias=0 changes nothing.
+UNIT_FLAGS = {"engine_f32_single": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"],
+              "engine_f32_double": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]}
 
 
 def _deps():
@@ -82,7 +89,9 @@ def _compile_units(out, extra_flags, verbose):
 
     def one(unit):
         obj = os.path.join(objdir, "%s.%d.o" % (unit, os.getpid()))
-        cmd = [hipcc] + HIPCC_FLAGS + extra_flags + ["-c", "-o", obj, os.path.join(CSRC, unit + ".hip")]
+        # a variant that names a scheduling strategy itself replaces the unit's (the option may be given once)
+        unit_flags = [] if any("amdgpu-sched-strategy" in f for f in extra_flags) else UNIT_FLAGS.get(unit, [])
+        cmd = [hipcc] + HIPCC_FLAGS + unit_flags + extra_flags + ["-c", "-o", obj, os.path.join(CSRC, unit + ".hip")]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         # hipcc's warnings (hundreds of "loop not unrolled" remarks for the run-time-spacing kernels) are shown only when
