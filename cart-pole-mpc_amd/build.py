@@ -23,8 +23,10 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize
 # results, 117.1 -> 119.8 M re-plans/s in two same-session A/Bs (round 4, tools/ab_both.sh; no spills instead of 4).  The
 # double kernels (one wave per SIMD, at the register limit) lose 0.4 % with it and 1.5 - 4 % with max-ilp, iterative-minreg,
 # iterative-maxocc and max-memory-clause, so they keep the default; amdgpu-schedule-metric-bias=0 changes nothing.
-UNIT_FLAGS = {"engine_f32_single": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"],
-              "engine_f32_double": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]}
+# Without the post-RA scheduler on top (it undoes part of that spacing): 119.9 -> 121.8 M; the double kernels lose 7.7 %
+# without it, so again only the float units.
+_F32_SCHED = ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-mllvm", "-enable-post-misched=0"]
+UNIT_FLAGS = {"engine_f32_single": _F32_SCHED, "engine_f32_double": _F32_SCHED}
 
 
 def _deps():
