@@ -192,6 +192,13 @@ __device__ __forceinline__ R group_last(R v, int gbase) {
 #define CPMPC_FUSED_GAMMA_AHEAD(R) (sizeof(R) == 8)
 #endif
 // unroll factor of the block-local sweep passes (LDS reads of several controls in flight)
+// The exit test's rounding floor (cpmpc_solver_opts.exit_defect_floor) in the DOUBLE kernels: left out by default.  In
+// double the floor is 3e-14 -- it could change an exit decision only where |D| is within mu x 3e-14 of the tolerance -- and
+// carrying the few instructions costs the fp64 fused kernel 1.6 % (4.845 -> 4.925 ms at B = 262 144, same-session A/B: the
+// kernel sits at its register limit and the extra live values reshuffle its spills).  1 compiles it in.
+#ifndef CPMPC_EXIT_FLOOR_F64
+#define CPMPC_EXIT_FLOOR_F64 0
+#endif
 #ifndef CPMPC_SWEEP_UNROLL
 #define CPMPC_SWEEP_UNROLL 5
 #endif

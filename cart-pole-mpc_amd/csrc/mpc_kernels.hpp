@@ -29,6 +29,9 @@
 #ifndef CPMPC_PF_BLOCK
 #define CPMPC_PF_BLOCK 256
 #endif
+#ifndef CPMPC_EXIT_FLOOR_F64
+#define CPMPC_EXIT_FLOOR_F64 0  // see mpc_fused.hpp
+#endif
 
 namespace cpmpc {
 
@@ -1112,15 +1115,16 @@ __global__ CPMPC_QPLS_BOUNDS void qp_ls_kernel(const SolverArgs<R, M> a) {
   const R D = gd - mu * cn;
   const R phi0 = f + mu * cn;
   // equality residuals at the rounding floor of the rollout count as zero in the exit test
-  R x_l1 = R(0);
-  for (int s = 1; s < S; ++s) {
-    R xv[NX];
-    unpack<R, NX>(a.zx[(int64_t)s * st + p], xv);
+  bool first_order;
+  if constexpr (sizeof(R) == 4 || CPMPC_EXIT_FLOOR_F64) {   // (the double kernels: see CPMPC_EXIT_FLOOR_F64)
+    R x_l1 = R(0);   // the size of the states: target and distance to it at the terminal node, times the number of intervals
 #pragma unroll
-    for (int t = 0; t < NX; ++t) x_l1 += Math<R>::fabs(xv[t]);
+    for (int t = 0; t < NX; ++t) x_l1 += Math<R>::fabs(tgt[t]) + Math<R>::fabs(e_term[t]);
+    const R D_exit = gd - mu * (cn > a.cn_floor_scale * R(S - 1) * x_l1 ? cn : R(0));
+    first_order = Math<R>::fabs(D_exit) < a.fo_tol;
+  } else {
+    first_order = Math<R>::fabs(D) < a.fo_tol;
   }
-  const R D_exit = gd - mu * (cn > a.cn_floor_scale * x_l1 ? cn : R(0));
-  const bool first_order = Math<R>::fabs(D_exit) < a.fo_tol;
 
   // ---- Armijo line search, lock-step over the wave ----------------------------------------------
   // Local convergence safeguard: a QP step that is tiny in every component is taken in full

@@ -890,8 +890,21 @@ static int solve(const orc_model* m, const orc_opt_params* p, const orc_solver_o
      * RK4 steps -- count as zero here: no iteration can remove them, and in single precision mu |c|_1 at that floor
      * (1e-6 .. 1e-4) would keep a converged controller iterating on noise for ever (round 4; in double the floor is
      * 3e-14 and changes nothing).  The merit and the Armijo test use the residuals as they are. */
+    /* the size of the states, taken at the terminal node (target and distance to it) times the number of intervals: the
+     * nodes of a plan that is near its targets are all about that large, and a plan that is not has residuals far above
+     * any rounding anyway */
     double x_l1 = 0.0;
-    for (int j = m->nx; j < m->nx * num_states(p); ++j) x_l1 += fabs(z[j]);
+    {
+      double w_t[ORC_MAXNX], tgt_t[ORC_MAXNX];
+      terminal_spec(m, p, set_point, w_t, tgt_t);
+      const int S_ = num_states(p);
+      for (int t = 0; t < m->nx; ++t) {
+        double d = z[m->nx * (S_ - 1) + t] - tgt_t[t];
+        if (is_angle(m, t)) d = orc_mod_pi(d);
+        x_l1 += fabs(tgt_t[t]) + fabs(d);
+      }
+      x_l1 *= (double)(S_ - 1);
+    }
     const double cn_floor = o->exit_defect_floor * (double)p->state_spacing * (double)ORC_EPS * x_l1;
     const double D_exit = gd - mu * (cn > cn_floor ? cn : 0.0);
     const int first_order = fabs(D_exit) < p->absolute_first_derivative_tol;
