@@ -190,6 +190,14 @@ static int create_impl(const cpmpc_params* params, const cpmpc_solver_opts* opts
                   "1.6 s; 2 of 16384 cold starts are beyond 1e-5 at 1.2 s); pass CPMPC_CREATE_ALLOW_LONG_HORIZON to "
                   "cpmpc_create_ex to solve it anyway", horizon, kMaxParityHorizon);
   }
+  // defaults first, then as many leading bytes as the caller's struct has: a caller compiled against an earlier header
+  // (a shorter struct: fields are only ever appended) keeps this library's defaults for the options it does not know
+  cpmpc_solver_opts merged;
+  cpmpc_default_solver_opts(&merged);
+  if (opts) memcpy(&merged, opts, opts_size);
+  if (!(merged.full_step_below >= 0.0) || !(merged.exit_defect_floor >= 0.0) || !std::isfinite(merged.full_step_below) ||
+      !std::isfinite(merged.exit_defect_floor))   // the two thresholds that switch a rule off at 0 (NaN fails both tests)
+    return fail(CPMPC_ERR_INVALID_ARG, "full_step_below and exit_defect_floor must be finite and >= 0 (0 disables the rule)");
   rc = check_device(device);
   if (rc) return rc;
   DeviceGuard guard(device);
@@ -197,10 +205,7 @@ static int create_impl(const cpmpc_params* params, const cpmpc_solver_opts* opts
   cpmpc_solver* s = new (std::nothrow) cpmpc_solver();
   if (!s) return fail(CPMPC_ERR_ALLOC, "out of host memory");
   s->params = *params;
-  // defaults first, then as many leading bytes as the caller's struct has: a caller compiled against an earlier header
-  // (a shorter struct: fields are only ever appended) keeps this library's defaults for the options it does not know
-  cpmpc_default_solver_opts(&s->opts);
-  if (opts) memcpy(&s->opts, opts, opts_size);
+  s->opts = merged;
   s->dtype = dtype;
   // default: refine where the control cost is weak (measured: include/cpmpc.h, CPMPC_CREATE_REFINE_QP)
   s->refine_qp = (flags & CPMPC_CREATE_REFINE_QP) != 0 ||

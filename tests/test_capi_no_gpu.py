@@ -183,6 +183,16 @@ def test_product_does_not_import_the_oracle():
                 assert "oracle" not in text.lower().replace("no cpu fallback", ""), os.path.join(base, name)
 
 
+def test_rule_thresholds_are_validated(lib, pkg):
+    """full_step_below / exit_defect_floor: finite and >= 0 (checked before any device is touched)."""
+    p = pkg.default_params()
+    for field in ("full_step_below", "exit_defect_floor"):
+        for bad in (-1.0, float("nan"), float("inf")):
+            o = pkg.capi.default_solver_opts(**{field: bad})
+            h = C.c_void_p()
+            assert lib.cpmpc_create(C.byref(p), C.byref(o), pkg.capi.F64, 8, 0, C.byref(h)) == pkg.capi.ERR_INVALID_ARG, (field, bad)
+
+
 def _plan(lib, hist, B=262144, T=8, intervals=4, dtype=1, window=40):
     h = (C.c_int64 * 16)(*([int(v) for v in hist] + [0] * (16 - len(hist))))
     out = (C.c_int32 * 32)()
