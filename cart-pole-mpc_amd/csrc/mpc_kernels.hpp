@@ -1131,8 +1131,10 @@ __global__ CPMPC_QPLS_BOUNDS void qp_ls_kernel(const SolverArgs<R, M> a) {
   // without the merit test (the l1 merit cannot resolve the decrease such a step brings, and rejects it)
   // (only the undamped step: one that is small because lambda is large is no sign of convergence)
   const bool tiny = dz_inf <= a.full_step_below && lam == R(0);
-  bool active = (status == kTermNone);
-  bool accepted = false;
+  // converged (first-order test and a tiny undamped step): the full step without a merit evaluation
+  const bool skip_merit = tiny && first_order;
+  bool active = (status == kTermNone) && !skip_merit;
+  bool accepted = (status == kTermNone) && skip_merit;
   R alpha = tiny ? R(1) : a_start, phi_t = R(0), f_t = f, cn_t = cn;
   int evals = 0;
   for (int t = 0; t < a.max_ls; ++t) {
@@ -1195,7 +1197,7 @@ __global__ CPMPC_QPLS_BOUNDS void qp_ls_kernel(const SolverArgs<R, M> a) {
   a.sc[SC_MU * st + p] = mu;
   a.sc[SC_F_LAST * st + p] = f_t;   // accepted: the trial's pieces; else f, cn as used above (unchanged iterate)
   a.sc[SC_CN_LAST * st + p] = cn_t;
-  if (accepted && status != kTermNonFinite) a.sc[SC_TRIAL * st + p] = R(1);
+  if (accepted && status != kTermNonFinite) a.sc[SC_TRIAL * st + p] = skip_merit ? R(0) : R(1);
   a.sc[SC_ALPHA * st + p] = a_start;
   a.ist[IS_STATUS * st + p] = status;
   a.ist[IS_LS_EVALS * st + p] += evals;

@@ -930,6 +930,18 @@ static int solve(const orc_model* m, const orc_opt_params* p, const orc_solver_o
     double alpha = tiny ? 1.0 : alpha_start;
     int accepted = 0, backtracked = 0;
     double phi_t = 0.0, f_t = 0.0, cn_t = 0.0;
+    if (first_order && tiny) {
+      /* Converged (round 4): the first-order test holds and the undamped QP step is tiny in every component.  The full
+       * step is taken and the iteration ends, WITHOUT evaluating the merit at the new point: nothing depends on that
+       * value any more (the tiny rule accepts any finite merit), and it is a whole rollout -- a quarter of the work of a
+       * settled controller's tick.  The reported cost and residual are those of the iterate the step was computed from. */
+      retract(m, p, o, z, dz, 1.0, zt);
+      memcpy(z, zt, sizeof(double) * (size_t)dim);
+      lambda *= o->lambda_scale_down;
+      if (lambda < o->lambda_min) lambda = 0.0;
+      term = ORC_TERM_SATISFIED_FIRST_ORDER_TOL;
+      break;
+    }
     for (int t = 0; t < o->max_line_search_iterations; ++t) {
       backtracked = (t > 0);
       retract(m, p, o, z, dz, alpha, zt);
