@@ -41,3 +41,22 @@ def test_default_configuration_balances(orc):
         sim.step(DYN_UI, 0.01, out.u[0])
     s = sim.get_state()
     assert abs(s[1] - np.pi / 2) < 1e-4 and abs(s[0]) < 1e-3 and abs(s[2]) < 1e-3 and abs(s[3]) < 1e-3
+
+
+def test_a_converged_step_is_taken_without_a_merit_evaluation(orc):
+    """DESIGN.md section 4 (round 4): once a controller has settled, the first-order test holds and the undamped QP step is
+    tiny, so the step is taken in full and the iteration ends without evaluating the merit at the new point -- one
+    iteration, no line-search evaluation, and the reported cost / residual are those of the iterate the step was computed
+    from (the initial ones of that solve).  With full_step_below = 0 (no tiny rule) the same tick costs one evaluation."""
+    p = orc.default_opt_params()
+    for opts, evals in ((None, 0), (orc.default_solver_opts(full_step_below=0.0), 1)):
+        sim = orc.Simulator()
+        opt = orc.Optimization(p) if opts is None else orc.Optimization(p, opts)
+        for _ in range(320):
+            out = opt.step(sim.get_state(), DYN_UI, 0.0)
+            sim.step(DYN_UI, 0.01, out.u[0])
+        so = out.solver_outputs
+        assert so.termination_state == orc.TERM["SATISFIED_FIRST_ORDER_TOL"] and so.iterations == 1
+        assert so.line_search_evals == evals
+        if evals == 0:
+            assert so.final_cost == so.initial_cost and so.final_eq_l1 == so.initial_eq_l1
