@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--pipeline", choices=["auto", "split", "fused"], default="auto")
+    ap.add_argument("--settle", type=int, default=0, help="closed_loop: untimed ticks first, from the benchmark's state "
+                    "distribution, so that the timed ones are settled ticks (tools/settled_trace.py reads the trace)")
     a = ap.parse_args()
     dt = torch.float32 if a.dtype == "f32" else torch.float64
     rng = np.random.default_rng(7)
@@ -66,6 +68,8 @@ def main():
         B = a.batch or 262144
         xs = np.stack([rng.uniform(-0.3, 0.3, B), np.pi / 2 + rng.uniform(-0.4, 0.4, B), rng.uniform(-0.5, 0.5, B),
                        rng.uniform(-1, 1, B)])
+        if a.settle:
+            xs = np.stack([rng.uniform(-0.6, 0.6, B), rng.uniform(-np.pi, np.pi, B), rng.uniform(-1, 1, B), rng.uniform(-3, 3, B)])
         sim = pkg.BatchSimulator(B, dtype=dt, device=0)
         sim.set_state(torch.tensor(xs, dtype=dt, device="cuda:0"))
         opt = pkg.BatchOptimization(pkg.default_params(), max_batch=B, dtype=dt, device=0)
@@ -74,8 +78,10 @@ def main():
         def step():
             o = opt.step(sim.get_state(), DYN_UI, 0.0, want_predicted=False, want_stats=True, out=out)
             sim.step(DYN_UI, 0.01, o.u[0].contiguous())
-    for _ in range(3):
+    for _ in range(3 + (a.settle if a.workload == "closed_loop" else 0)):
         step()
+        if a.settle:
+            torch.cuda.synchronize()   # a controller acts on u every tick: the stage plan then follows the tick before
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
