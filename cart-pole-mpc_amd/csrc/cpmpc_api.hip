@@ -277,8 +277,8 @@ static int create_impl(const cpmpc_params* params, const cpmpc_solver_opts* opts
     delete s;
     return fail(CPMPC_ERR_HIP, "hipMemcpy failed: %s", hipGetErrorString(e));
   }
-  // index list of the staged fused pipeline (4 bytes per problem + two counters): allocated here, never in a step
-  if (hipMalloc((void**)&s->active, ((size_t)s->cap + 2 * kHostSlots) * sizeof(int32_t)) != hipSuccess) {
+  // index list of the staged fused pipeline (4 bytes per problem + three counters per host slot): allocated here, never in a step
+  if (hipMalloc((void**)&s->active, ((size_t)s->cap + 3 * kHostSlots) * sizeof(int32_t)) != hipSuccess) {
     (void)hipGetLastError();
     s->active = nullptr;  // staging stays off for this handle (same results, single launch)
   }

@@ -213,6 +213,8 @@ static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* 
   const dim3 gridB = grid_for(B);
   ProfSpan sp;
 
+  // (the first compaction's counter: cleared by prepare_kernel whether or not this step turns out to be staged)
+  a.stage_count0 = (use_fused(s) && s->active != nullptr) ? s->active + s->cap + 3 * slot : nullptr;
   span_begin(s, CPMPC_KERNEL_PREPARE, stream, &sp);
   hipLaunchKernelGGL((prepare_kernel<R, M>), dim3((unsigned)((B + CPMPC_PF_BLOCK - 1) / CPMPC_PF_BLOCK)), dim3(CPMPC_PF_BLOCK), 0, stream, a);
   span_end(s, stream, &sp);
@@ -238,25 +240,23 @@ static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* 
     span_end(s, stream, &sp);
     for (int stage = 0; stage + 1 < n_stages; ++stage) {
       const int done = bounds[stage + 1];
-      int32_t* const counters = s->active + s->cap + 2 * slot;  // a pair per host slot: chunks of a pipelined host step run concurrently
-      int32_t* count = counters + (stage & 1);                  // two counters: this compaction and the one before
-      a.prev_count = stage ? counters + ((stage - 1) & 1) : nullptr;
+      // three counters per host slot (chunks of a pipelined host step run concurrently), rotating: this compaction's, the
+      // one before (prev_count), and the next one's, which this compaction clears; prepare_kernel cleared counters[0]
+      int32_t* const counters = s->active + s->cap + 3 * slot;
+      int32_t* count = counters + stage % 3;
+      a.prev_count = stage ? counters + (stage - 1) % 3 : nullptr;
       a.prev_total = B;
       a.remaining = total - done;
       span_begin(s, CPMPC_KERNEL_FUSED, stream, &sp);
-      const hipError_t memset_rc = hipMemsetAsync(count, 0, sizeof(int32_t), stream);
       hipLaunchKernelGGL((compact_active_kernel<M>), dim3((unsigned)((B + 1023) / 1024)), dim3(1024), 0, stream,
                          (const int32_t*)(a.ist + (size_t)IS_STATUS * (size_t)s->cap),
-                         (const int32_t*)(a.ist + (size_t)IS_ITERS * (size_t)s->cap), total, B, s->active + col0, count);
+                         (const int32_t*)(a.ist + (size_t)IS_ITERS * (size_t)s->cap), total, B, s->active + col0, count,
+                         counters + (stage + 1) % 3);
       a.active_list = s->active + col0;
       a.active_count = count;
       const int k = bounds[stage + 2] - done;
       launch_fused<R, M>(a, s->S - 1, s->SP, k, s->refine_qp, stream);
-      span_end(s, stream, &sp);  // the span is closed (its events recycled) before any early return
-      if (memset_rc != hipSuccess) {
-        if (col0 + B > s->prev_B) s->prev_B = col0 + B;  // prepare has already shifted the warm start: keep the handle consistent
-        return fail(CPMPC_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(memset_rc));
-      }
+      span_end(s, stream, &sp);
     }
   } else {
     for (int it = 0; it < (int)s->params.max_iterations; ++it) {

@@ -158,6 +158,7 @@ struct SolverArgs {
   const int32_t* prev_count;  // active problems at the previous compaction (nullptr: prev_total)
   int64_t prev_total;
   int remaining;           // iterations still to run, this stage included
+  int32_t* stage_count0;   // prepare_kernel clears it: the first compaction's counter (nullptr: one launch, no compaction)
   // feedback for the host's staging plan (finalize_kernel): histogram of this step's iterations per problem
   int32_t* fb_host;        // host-mapped [reporter][kFbBins + 1]: a workgroup's histogram, then fb_seq (written last); nullptr: off
   int fb_seq;
@@ -244,7 +245,12 @@ __device__ __forceinline__ void wrap_angles(R (&x)[M::NX]) {
 // ------------------------------------------------------------------------------------------------
 template <typename Tag>  // Tag = the model policy: one instance per translation unit of the library (engine_*.hip)
 __global__ __launch_bounds__(1024) void compact_active_kernel(const int32_t* status, const int32_t* iters,
-                                                              int iter_cap, int64_t B, int32_t* list, int32_t* count) {
+                                                              int iter_cap, int64_t B, int32_t* list, int32_t* count,
+                                                              int32_t* clear_for_next) {
+  // three counters rotate through the stages: this compaction counts into `count`, the stage it feeds also reads the one
+  // before, and the third -- nobody's until the next compaction, whose `count` it will be -- is cleared here (no memset
+  // between the launches; prepare_kernel cleared the first one)
+  if (blockIdx.x == 0 && threadIdx.x == 0) *clear_for_next = 0;
   // one atomic per 1024-thread workgroup (16 waves): the wave totals go through LDS, wave 0 reserves the block's range.
   // (One atomic per WAVE on a single counter serialised: 4096 of them took 42 us at B = 262144, profiles/r02b_closed_loop.)
   __shared__ int wave_total[16];
@@ -274,6 +280,7 @@ __global__ __launch_bounds__(CPMPC_PF_BLOCK) void prepare_kernel(const SolverArg
   constexpr int NX = M::NX;
   const unsigned p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= a.B) return;
+  if (p == 0 && a.stage_count0 != nullptr) *a.stage_count0 = 0;  // the counter of the first compaction of this step
   const int64_t st = a.stride;
   const typename M::Consts k = load_consts(a, p);
   const ExtForce<R> fe{R(0), R(0), R(0)};
