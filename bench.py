@@ -447,6 +447,11 @@ def variants(torch, pkg, args, tdt, dev, local_rank, x0, B):
     xs = np.stack([rng.uniform(-0.3, 0.3, B), np.pi / 2 + rng.uniform(-0.4, 0.4, B), rng.uniform(-0.5, 0.5, B),
                    rng.uniform(-1, 1, B)])
 
+    # the torch kernels the loops below call for their statistics, loaded before anything is timed (on a fresh box with a
+    # cold page cache the first use of one costs tens of milliseconds: seen as 2.6 instead of 1.9 ms per tick once)
+    _w = torch.zeros(8, dtype=torch.int32, device=dev)
+    _ = _w.float().mean().item(), (_w.double() - 1.0).abs().median().item(), (_w.float() < 0.1).float().mean().item()
+
     def closed_loop(dt_torch, settle=0, **over):
         sim = pkg.BatchSimulator(B, dtype=dt_torch, device=local_rank)
         sim.set_state(torch.tensor(xs, dtype=dt_torch, device=dev))
