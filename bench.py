@@ -30,6 +30,7 @@ timed the same way, with its own roofline and its control sequences compared wit
 Prints ONE JSON line on rank 0 (see the driver contract in the task description).
 """
 import argparse
+import gc
 import importlib
 import json
 import os
@@ -295,6 +296,7 @@ def timed_region(torch, dist, sharding, opt, x0, outs, gather, steps, warmup, de
     out = None
     for _ in range(warmup):
         out = one_step()
+    gc.collect()   # no destructor of an earlier leg's handle inside the timed steps (see quiesce)
     fence()
     opt.profile_enable(True)
     opt.profile_reset()
@@ -411,6 +413,15 @@ def issue_of(clock_rec, dtype, B):
     return out
 
 
+def quiesce(torch):
+    """Before a timed loop: run the pending destructors NOW.  A solver handle that has gone out of scope is destroyed when
+    Python's collector gets to it, and destroying one frees gigabytes of workspace (hipFree synchronises the device) and a
+    few thousand events -- seen landing inside the first closed loop of the default run, 1.95 -> 2.7 .. 2.95 ms per tick,
+    and not with --steps 100, because the collector's trigger is a count of allocations."""
+    gc.collect()
+    torch.cuda.synchronize()
+
+
 def variants(torch, pkg, args, tdt, dev, local_rank, x0, B):
     """Secondary measurements of SURVEY.md 8(d), outside the timed region and never `value`:
     (1) the same cold-start re-plan with the reference's exit tolerances enabled (optimization.hpp:30-34:
@@ -420,6 +431,7 @@ def variants(torch, pkg, args, tdt, dev, local_rank, x0, B):
     (3) one controller at 100 Hz through the C++ facade (viz/src/application.ts:393-399)."""
     res = {}
     p1 = pkg.default_params(max_iterations=args.iters)
+    quiesce(torch)
     opt = pkg.BatchOptimization(p1, max_batch=B, dtype=tdt, device=local_rank)
     opt.set_pipeline(args.pipeline)
     out = pkg.BatchOutputs()
@@ -462,7 +474,7 @@ def variants(torch, pkg, args, tdt, dev, local_rank, x0, B):
             o = opt.step(sim.get_state(), DYN_UI, 0.0, want_predicted=False, want_stats=True, out=out)
             sim.step(DYN_UI, 0.01, o.u[0].contiguous())
         its = 0.0
-        torch.cuda.synchronize()
+        quiesce(torch)
         t0 = time.perf_counter()
         for k in range(ticks):
             o = opt.step(sim.get_state(), DYN_UI, 0.0, want_predicted=False, want_stats=True, out=out)
@@ -472,7 +484,9 @@ def variants(torch, pkg, args, tdt, dev, local_rank, x0, B):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / ticks
         err = (sim.get_state()[1] - np.pi / 2).abs()
-        return {"ticks/s (controllers x ticks)": B / dt, "ms_per_tick": dt * 1e3, "ticks": ticks, "stage_plan_last_tick": opt.stage_plan(),
+        plan = opt.stage_plan()
+        opt.close()
+        return {"ticks/s (controllers x ticks)": B / dt, "ms_per_tick": dt * 1e3, "ticks": ticks, "stage_plan_last_tick": plan,
                 "mean_iterations_last_10_ticks": its,
                 "median_abs_pole_angle_error_after_0.5s": float(err.median().item()),
                 "fraction_within_0.1rad_after_0.5s": float((err < 0.1).float().mean().item())}
@@ -536,6 +550,7 @@ def per_problem_variant(torch, pkg, args, dev, local_rank, B, lanes=4096, steps=
         dyn = torch.tensor(dyn_np, dtype=dt, device=dev)
         sp = torch.tensor(sp_np, dtype=dt, device=dev)
         tw = torch.tensor(tw_np, dtype=dt, device=dev)
+        quiesce(torch)
         opt = pkg.BatchOptimization(pkg.default_params(**over), max_batch=B, dtype=dt, device=local_rank)
         opt.set_pipeline(args.pipeline)
         out = pkg.BatchOutputs()
@@ -613,7 +628,7 @@ def split_streams_variant(torch, pkg, args, dev, local_rank, B, steps=20):
 
             for _ in range(3):
                 step()
-            torch.cuda.synchronize()
+            quiesce(torch)
             t0 = time.perf_counter()
             for _ in range(steps):
                 step()
@@ -865,6 +880,7 @@ def run_rank(args):
                                     "timed region in fp64 at the same batch, timed the same way"}
             u64 = o64.u.cpu().numpy()
             st64 = o64.status.cpu().numpy()
+            opt64.close()   # now, not whenever the collector gets to it (a 2 GB hipFree inside somebody's timed loop)
             del opt64, x64, outs64, o64
         except Exception as exc:  # noqa: BLE001
             line["fp64"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
