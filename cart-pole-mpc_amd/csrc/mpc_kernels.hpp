@@ -32,6 +32,9 @@
 #ifndef CPMPC_EXIT_FLOOR_F64
 #define CPMPC_EXIT_FLOOR_F64 0  // see mpc_fused.hpp
 #endif
+#ifndef CPMPC_SKIP_MERIT
+#define CPMPC_SKIP_MERIT 1      // 0: A/B build that evaluates the merit of a converged step as rounds 1-3 did (NOT the specification)
+#endif
 
 namespace cpmpc {
 
@@ -1139,7 +1142,7 @@ __global__ CPMPC_QPLS_BOUNDS void qp_ls_kernel(const SolverArgs<R, M> a) {
   // (only the undamped step: one that is small because lambda is large is no sign of convergence)
   const bool tiny = dz_inf <= a.full_step_below && lam == R(0);
   // converged (first-order test and a tiny undamped step): the full step without a merit evaluation
-  const bool skip_merit = tiny && first_order;
+  const bool skip_merit = CPMPC_SKIP_MERIT && tiny && first_order;
   bool active = (status == kTermNone) && !skip_merit;
   bool accepted = (status == kTermNone) && skip_merit;
   R alpha = tiny ? R(1) : a_start, phi_t = R(0), f_t = f, cn_t = cn;
