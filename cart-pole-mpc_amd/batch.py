@@ -93,10 +93,11 @@ class BatchOptimization:
     """B independent pendulum::Optimization controllers solved in lock-step on one GPU."""
 
     def __init__(self, params, max_batch, dtype=torch.float32, device=None, opts=None, model="single",
-                 allow_long_horizon=False, refine_qp=None):
-        """allow_long_horizon: accept window_length * control_dt beyond cpmpc_max_parity_horizon() (1.0 s), where the
-        condensed QP is no longer held to 1e-5 of a full-space solve on every problem (include/cpmpc.h,
-        CPMPC_CREATE_ALLOW_LONG_HORIZON); without it such parameters raise CpmpcError(ERR_UNSUPPORTED).
+                 allow_long_horizon=False, refine_qp=None, strict_horizon=False):
+        """strict_horizon: refuse (CpmpcError(ERR_UNSUPPORTED)) window_length * control_dt beyond
+        cpmpc_max_parity_horizon() (1.0 s), where the condensed QP is no longer held to 1e-5 of a full-space solve on
+        every problem (include/cpmpc.h, CPMPC_CREATE_STRICT_HORIZON).  By default every horizon the reference accepts is
+        accepted, with one warning per process; allow_long_horizon=True silences the warning.
         refine_qp: True / False force on / off the refinement of the whole QP solution in the fp64 fused kernels
         (CPMPC_CREATE_[NO_]REFINE_QP: 7 % slower); None = the library's default: on when u_cost_weight < 0.05."""
         lib = capi.load()
@@ -115,6 +116,7 @@ class BatchOptimization:
         self._h = C.c_void_p()
         info = capi.CreateInfo(struct_size=C.sizeof(capi.CreateInfo),
                                flags=(capi.CREATE_ALLOW_LONG_HORIZON if allow_long_horizon else 0)
+                               | (capi.CREATE_STRICT_HORIZON if strict_horizon else 0)
                                | (0 if refine_qp is None else (capi.CREATE_REFINE_QP if refine_qp else capi.CREATE_NO_REFINE_QP)),
                                dtype=_CAPI_DTYPE[dtype], model=self.model, device=self.device, reserved=0,
                                max_batch=self.max_batch, params=C.pointer(params),

@@ -130,6 +130,8 @@ class StepHostOutputs(C.Structure):
 CREATE_ALLOW_LONG_HORIZON = 1
 CREATE_REFINE_QP = 2
 CREATE_NO_REFINE_QP = 4
+CREATE_STRICT_HORIZON = 8
+SOLVER_OPTS_SIZE_POSITIONAL = 128
 
 
 class CreateInfo(C.Structure):

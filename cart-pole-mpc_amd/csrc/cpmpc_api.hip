@@ -174,21 +174,35 @@ static int create_impl(const cpmpc_params* params, const cpmpc_solver_opts* opts
   if (max_batch < 1 || max_batch > (1ll << 30)) return fail(CPMPC_ERR_INVALID_ARG, "max_batch must be in [1, 2^30]");
   int rc = validate_params(params);
   if (rc) return rc;
-  if ((flags & ~(uint32_t)(CPMPC_CREATE_ALLOW_LONG_HORIZON | CPMPC_CREATE_REFINE_QP | CPMPC_CREATE_NO_REFINE_QP)) != 0)
+  if ((flags & ~(uint32_t)(CPMPC_CREATE_ALLOW_LONG_HORIZON | CPMPC_CREATE_REFINE_QP | CPMPC_CREATE_NO_REFINE_QP |
+                           CPMPC_CREATE_STRICT_HORIZON)) != 0)
     return fail(CPMPC_ERR_INVALID_ARG, "unknown creation flags 0x%x", flags);
   if ((flags & CPMPC_CREATE_REFINE_QP) && (flags & CPMPC_CREATE_NO_REFINE_QP))
     return fail(CPMPC_ERR_INVALID_ARG, "CPMPC_CREATE_REFINE_QP and CPMPC_CREATE_NO_REFINE_QP exclude each other");
-  if (opts != nullptr && (opts_size < sizeof(int32_t) || opts_size > sizeof(cpmpc_solver_opts)))
-    return fail(CPMPC_ERR_INVALID_ARG, "opts_size %zu is not the size of any cpmpc_solver_opts this library knows (at most %zu)",
-                opts_size, sizeof(cpmpc_solver_opts));
+  // the struct in some release: the leading int (padded to 8) and a whole number of doubles, from the first release's 13
+  // (104 bytes) to this one's; a size that splits a field is nobody's struct
+  if (opts != nullptr && (opts_size < 104 || opts_size > sizeof(cpmpc_solver_opts) || opts_size % 8 != 0))
+    return fail(CPMPC_ERR_INVALID_ARG, "opts_size %zu is not the size of any cpmpc_solver_opts this library knows (8 + 8 k "
+                "bytes, 104 .. %zu)", opts_size, sizeof(cpmpc_solver_opts));
   {
+    // Every horizon the reference's constructor accepts is accepted (optimization.cc:13-22: this is a drop-in); beyond
+    // cpmpc_max_parity_horizon() the first handle of the process says so once, and CPMPC_CREATE_STRICT_HORIZON refuses.
     const double horizon = (double)params->window_length * params->control_dt;
-    if (horizon > kMaxParityHorizon * (1.0 + 1e-9) && !(flags & CPMPC_CREATE_ALLOW_LONG_HORIZON))
-      return fail(CPMPC_ERR_UNSUPPORTED,
-                  "horizon window_length * control_dt = %.3f s exceeds %.1f s, the longest the condensed QP is held to 1e-5 of a "
-                  "full-space solve on every problem (state elimination through an unstable plant loses ~3 digits per QP at "
-                  "1.6 s; 2 of 16384 cold starts are beyond 1e-5 at 1.2 s); pass CPMPC_CREATE_ALLOW_LONG_HORIZON to "
-                  "cpmpc_create_ex to solve it anyway", horizon, kMaxParityHorizon);
+    if (horizon > kMaxParityHorizon * (1.0 + 1e-9)) {
+      if (flags & CPMPC_CREATE_STRICT_HORIZON)
+        return fail(CPMPC_ERR_UNSUPPORTED,
+                    "horizon window_length * control_dt = %.3f s exceeds %.1f s, the longest the condensed QP is held to 1e-5 of a "
+                    "full-space solve on every problem (state elimination through an unstable plant loses ~3 digits per QP at "
+                    "1.6 s; 2 of 16384 cold starts are beyond 1e-5 at 1.2 s), and CPMPC_CREATE_STRICT_HORIZON was given",
+                    horizon, kMaxParityHorizon);
+      static std::atomic<bool> warned{false};
+      if (!(flags & CPMPC_CREATE_ALLOW_LONG_HORIZON) && !warned.exchange(true))
+        fprintf(stderr,
+                "cpmpc: horizon window_length * control_dt = %.3f s is beyond %.1f s (cpmpc_max_parity_horizon): solved as "
+                "asked, but cold starts far from the optimum may differ from a full-space solve by more than 1e-5 on a "
+                "few problems in 10^4 (include/cpmpc.h, CPMPC_CREATE_STRICT_HORIZON).  Said once per process.\n",
+                horizon, kMaxParityHorizon);
+    }
   }
   // defaults first, then as many leading bytes as the caller's struct has: a caller compiled against an earlier header
   // (a shorter struct: fields are only ever appended) keeps this library's defaults for the options it does not know
@@ -299,12 +313,12 @@ static int create_impl(const cpmpc_params* params, const cpmpc_solver_opts* opts
 
 extern "C" int cpmpc_create_model(const cpmpc_params* params, const cpmpc_solver_opts* opts, int dtype,
                                   int64_t max_batch, int device, int model, cpmpc_solver** out) {
-  return create_impl(params, opts, sizeof(cpmpc_solver_opts), dtype, max_batch, device, model, 0, out);
+  return create_impl(params, opts, CPMPC_SOLVER_OPTS_SIZE_POSITIONAL, dtype, max_batch, device, model, 0, out);
 }
 
 extern "C" int cpmpc_create(const cpmpc_params* params, const cpmpc_solver_opts* opts, int dtype,
                             int64_t max_batch, int device, cpmpc_solver** out) {
-  return create_impl(params, opts, sizeof(cpmpc_solver_opts), dtype, max_batch, device, CPMPC_MODEL_SINGLE, 0, out);
+  return create_impl(params, opts, CPMPC_SOLVER_OPTS_SIZE_POSITIONAL, dtype, max_batch, device, CPMPC_MODEL_SINGLE, 0, out);
 }
 
 extern "C" int cpmpc_create_ex(const cpmpc_create_info* info, cpmpc_solver** out) {
@@ -525,7 +539,9 @@ static int plan_from_histogram(const double* hist, double n_hist, int64_t B, int
 // the planner alone, for tests and tools (no device, no handle): hist[16] as finalize_kernel reports it
 extern "C" int cpmpc_plan_stages_from_histogram(const int64_t* hist, int64_t B, int max_iterations, int intervals, int dtype,
                                                 int window_length, int32_t* bounds, int capacity) {
-  if (!hist || !bounds || B < 1 || max_iterations < 1 || max_iterations > kMaxStages || intervals < 1 || intervals > 64 ||
+  // (max_iterations <= kFbBins - 1: with more, the last bin -- "this many or more" -- would stand for problems that
+  // stopped early as well as for those that ran to the cap, and surv[] could not tell them apart)
+  if (!hist || !bounds || B < 1 || max_iterations < 1 || max_iterations > kFbBins - 1 || intervals < 1 || intervals > 64 ||
       window_length < 1 || capacity < max_iterations + 1 || (dtype != CPMPC_F32 && dtype != CPMPC_F64))
     return -1;
   double h[kFbBins], n_hist = 0.0;
@@ -568,20 +584,28 @@ int cpmpc_plan_stages(cpmpc_solver* s, int slot, int64_t B, bool exits, int* bou
   // default: only batches beyond one round of resident waves (2 per SIMD) are staged at all -- a smaller one ends with
   // its slowest wave either way
   if ((B * (int64_t)L + 63) / 64 <= 2048) return finish(1);
-  if (s->fb_host == nullptr || T > kMaxStages) return fixed(s->stage_first, s->stage_next);
+  if (s->fb_host == nullptr || T > kFbBins - 1) return fixed(s->stage_first, s->stage_next);  // (the last bin must mean "the cap")
   // the counts of the reporting workgroups that carry the same step's stamp as the first one (a step still running has
   // stamped only some: they wait for a later plan)
   const int32_t* fb = s->fb_host + (size_t)slot * kFbReporters * (kFbBins + 1);
-  const int seq = __atomic_load_n(&fb[kFbBins], __ATOMIC_ACQUIRE);
+  // Relaxed loads on purpose: the kernel publishes with relaxed system-scope stores (a release there writes the L2 back,
+  // 29 -> 94 us of finalize), so no ordering is promised and none is pretended here.  A reporter's stamp is read before
+  // AND after its counts; a block whose stamp moved in between (the next step's finalize is writing it) is left out, like
+  // one that has not been written yet.  What can still slip through is a block whose counts belong to a newer step than
+  // its stamp: a hint that is one step off costs speed, never results -- the plan decides only where the launches are cut.
+  const int seq = __atomic_load_n(&fb[kFbBins], __ATOMIC_RELAXED);
   double hist[kFbBins], n_hist = 0.0;
   for (int b = 0; b < kFbBins; ++b) hist[b] = 0.0;
   for (int r = 0; seq != 0 && r < s->fb_reporters[slot]; ++r) {
     const int32_t* rep = fb + (size_t)r * (kFbBins + 1);
-    if (__atomic_load_n(&rep[kFbBins], __ATOMIC_ACQUIRE) != seq) continue;
+    if (__atomic_load_n(&rep[kFbBins], __ATOMIC_RELAXED) != seq) continue;
+    double c[kFbBins];
+    for (int b = 0; b < kFbBins; ++b) c[b] = (double)__atomic_load_n(&rep[b], __ATOMIC_RELAXED);
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);  // (host-side only: keeps the compiler and the CPU from hoisting the re-read)
+    if (__atomic_load_n(&rep[kFbBins], __ATOMIC_RELAXED) != seq) continue;
     for (int b = 0; b < kFbBins; ++b) {
-      const double c = (double)__atomic_load_n(&rep[b], __ATOMIC_RELAXED);
-      hist[b] += c;
-      n_hist += c;
+      hist[b] += c[b];
+      n_hist += c[b];
     }
   }
   if (seq == 0 || n_hist <= 0.0) return fixed(s->stage_first, s->stage_next);  // nothing to plan from yet
@@ -1138,6 +1162,7 @@ extern "C" int cpmpc_sharded_create(const cpmpc_params* params, const cpmpc_solv
   info.max_batch = max_batch;
   info.params = params;
   info.opts = opts;
+  info.opts_size = opts ? CPMPC_SOLVER_OPTS_SIZE_POSITIONAL : 0;  // a positional constructor: the struct as it was frozen
   return cpmpc_sharded_create_ex(&info, devices, n_devices, out);
 }
 

@@ -1245,6 +1245,7 @@ __global__ __launch_bounds__(CPMPC_PF_BLOCK) void finalize_kernel(const SolverAr
     int32_t* const dst = a.fb_host + (size_t)(blockIdx.x / (unsigned)a.fb_stride) * (kFbBins + 1);
     // relaxed stores, no system-scope fence: a release at system scope writes the whole L2 back (this kernel's own
     // outputs: 29 -> 94 us measured), and all the host needs is a hint -- a count read half-updated costs nothing but speed
+    // (the host reads the stamp before and after the counts and drops a block whose stamp moved: cpmpc_plan_stages)
     if (threadIdx.x < kFbBins) __hip_atomic_store(&dst[threadIdx.x], bins[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(&dst[kFbBins], a.fb_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

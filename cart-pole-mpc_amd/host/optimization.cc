@@ -59,12 +59,12 @@ cpmpc_params ToCParams(const OptimizationParams& p) {
   throw std::runtime_error(text);
 }
 
-Optimization::Optimization(const OptimizationParams& params, std::size_t max_batch, int device, bool allow_long_horizon)
+Optimization::Optimization(const OptimizationParams& params, std::size_t max_batch, int device, bool strict_horizon)
     : params_(params), max_batch_(max_batch) {
   const cpmpc_params c = ToC(params);
   cpmpc_create_info info{};
   info.struct_size = sizeof info;
-  info.flags = allow_long_horizon ? CPMPC_CREATE_ALLOW_LONG_HORIZON : 0u;
+  info.flags = strict_horizon ? CPMPC_CREATE_STRICT_HORIZON : 0u;
   info.dtype = CPMPC_F64;  // fp64, like the reference.
   info.model = CPMPC_MODEL_SINGLE;
   info.device = device;

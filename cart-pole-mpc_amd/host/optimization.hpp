@@ -91,11 +91,12 @@ class Optimization {
  public:
   // Throws std::invalid_argument on the reference constructor's precondition failures
   // (optimization.cc:13-22) and std::runtime_error if no gfx950 device / library is usable.
-  // allow_long_horizon: accept window_length * control_dt beyond 1.0 s (cpmpc_max_parity_horizon), where eliminating
-  // the states through the unstable plant no longer reproduces a full-space solve to 1e-5 on every cold start
-  // (include/cpmpc.h, CPMPC_CREATE_ALLOW_LONG_HORIZON); without it such parameters throw std::runtime_error.
+  // Every horizon the reference's constructor accepts is accepted (optimization.cc:13-22).  strict_horizon: throw
+  // std::runtime_error for window_length * control_dt beyond 1.0 s (cpmpc_max_parity_horizon), where eliminating the states
+  // through the unstable plant no longer reproduces a full-space solve to 1e-5 on every cold start (include/cpmpc.h,
+  // CPMPC_CREATE_STRICT_HORIZON); without it the library says so once per process on stderr and solves.
   explicit Optimization(const OptimizationParams& params, std::size_t max_batch = 1, int device = 0,
-                        bool allow_long_horizon = false);
+                        bool strict_horizon = false);
   ~Optimization();
   Optimization(const Optimization&) = delete;
   Optimization& operator=(const Optimization&) = delete;

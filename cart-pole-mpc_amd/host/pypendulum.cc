@@ -139,7 +139,7 @@ PYBIND11_MODULE(pypendulum, m) {
   py::class_<Optimization>(m, "Optimization")
       .def(py::init<const OptimizationParams&>())
       .def(py::init<const OptimizationParams&, std::size_t, int, bool>(), py::arg("params"), py::arg("max_batch"),
-           py::arg("device") = 0, py::arg("allow_long_horizon") = false)
+           py::arg("device") = 0, py::arg("strict_horizon") = false)
       .def("step", &Optimization::Step)
       .def("step_batch", &StepBatchArrays<Optimization>, py::arg("states"), py::arg("dynamics_params"),
            py::arg("b_x_set_point"), py::arg("want_predicted") = true)
@@ -161,7 +161,7 @@ PYBIND11_MODULE(pypendulum, m) {
 
   py::class_<ShardedOptimization>(m, "ShardedOptimization")
       .def(py::init<const OptimizationParams&, std::size_t, const std::vector<int>&, bool>(), py::arg("params"),
-           py::arg("max_batch"), py::arg("devices") = std::vector<int>{}, py::arg("allow_long_horizon") = false)
+           py::arg("max_batch"), py::arg("devices") = std::vector<int>{}, py::arg("strict_horizon") = false)
       .def("step_batch", &StepBatchArrays<ShardedOptimization>, py::arg("states"), py::arg("dynamics_params"),
            py::arg("b_x_set_point"), py::arg("want_predicted") = true)
       .def("reset", &ShardedOptimization::Reset)

@@ -17,12 +17,12 @@ cpmpc_params ToCParams(const OptimizationParams& p);  // optimization.cc
 }
 
 ShardedOptimization::ShardedOptimization(const OptimizationParams& params, std::size_t max_batch,
-                                         const std::vector<int>& devices, bool allow_long_horizon)
+                                         const std::vector<int>& devices, bool strict_horizon)
     : params_(params), max_batch_(max_batch) {
   const cpmpc_params c = ToCParams(params);
   cpmpc_create_info info{};
   info.struct_size = sizeof info;
-  info.flags = allow_long_horizon ? CPMPC_CREATE_ALLOW_LONG_HORIZON : 0u;
+  info.flags = strict_horizon ? CPMPC_CREATE_STRICT_HORIZON : 0u;
   info.dtype = CPMPC_F64;
   info.model = CPMPC_MODEL_SINGLE;
   info.max_batch = static_cast<std::int64_t>(max_batch);

@@ -22,7 +22,7 @@ class ShardedOptimization {
   // devices: HIP device of each shard (a device may appear more than once); empty = every visible gfx950 device.
   // max_batch is the TOTAL number of controllers.  Throws like Optimization's constructor.
   explicit ShardedOptimization(const OptimizationParams& params, std::size_t max_batch,
-                               const std::vector<int>& devices = {}, bool allow_long_horizon = false);
+                               const std::vector<int>& devices = {}, bool strict_horizon = false);
   ~ShardedOptimization();
   ShardedOptimization(const ShardedOptimization&) = delete;
   ShardedOptimization& operator=(const ShardedOptimization&) = delete;

@@ -102,8 +102,9 @@ typedef struct cpmpc_solver_opts {
                              * |x_{S-1,t} - target_t|) -- the size of the states, taken at the terminal node, times the number of
                              * intervals (eps of the kernels' arithmetic): equality residuals of that size are the rounding of
                              * the rollout itself -- state_spacing RK4 steps -- and no iteration can remove them.  In fp64
-                             * that floor is 3e-14 and changes nothing (the CPMPC_F64 kernels do not even carry the test:
-                             * 1.6 % of their time for a decision that cannot differ); in fp32 it is 1.5e-5, and it is what lets settled
+                             * that floor would be 3e-14: the rule is a SINGLE-PRECISION rule -- CPMPC_F64 handles ignore this
+                             * option (their kernels do not carry the test, and neither does the double CPU check: one exit
+                             * rule in the parity dtype); in fp32 it is 1.5e-5, and it is what lets settled
                              * controllers leave after one iteration at the reference's tolerance of 1e-6 instead of
                              * iterating on noise (DESIGN.md sections 4 and 6.4; default 2, 0 disables; appended in round 4).
                              * Measured, fp32, 65 536 settled controllers: 0 -> 2.8 iterations per tick, 2 -> 1.8, 8 -> 1.0,
@@ -132,19 +133,27 @@ int cpmpc_create(const cpmpc_params* params, const cpmpc_solver_opts* opts /*nul
 void cpmpc_destroy(cpmpc_solver* s);
 
 /* The same constructor with its arguments in a size-versioned struct, plus what the positional forms cannot express:
- *   flags      CPMPC_CREATE_ALLOW_LONG_HORIZON: accept a horizon window_length * control_dt beyond
- *              cpmpc_max_parity_horizon().  cpmpc_create / cpmpc_create_model return CPMPC_ERR_UNSUPPORTED for those:
- *              the QP is solved by eliminating the states through the shooting recursion, and through more than
+ *   flags      CPMPC_CREATE_STRICT_HORIZON: refuse (CPMPC_ERR_UNSUPPORTED) a horizon window_length * control_dt beyond
+ *              cpmpc_max_parity_horizon().  By DEFAULT every horizon the reference's constructor accepts
+ *              (optimization.cc:13-22) is accepted, by every entry point -- the library is a drop-in -- and the first
+ *              such handle of a process writes one warning to stderr (CPMPC_CREATE_ALLOW_LONG_HORIZON, the opt-in of
+ *              round 4 when the refusal was the default, is still accepted and now only silences that warning).  What the
+ *              bound means: the QP is solved by eliminating the states through the shooting recursion, and through more than
  *              ~1 s of the default pole (unstable at e^{6.3 t}) that loses digits against a full-space KKT solve with
  *              pivoting -- measured at control_dt 0.01 (profiles/r04_parity_sweep.json): window_length 80 and 100 keep
  *              every one of 32 768 cold-start problems within 3e-6 / 4e-7 of the CPU check (three to eight iterations);
  *              at 120, 2 of 16 384 are beyond 1e-5 (worst 1.6e-5); at 160, 0.4 % are (worst 1e-2 .. 0.4 depending on
- *              the sample).  With the flag such a horizon is solved as it always was; warm-started closed loops are
- *              not affected in practice, cold starts far from the optimum are.
+ *              the sample).  Warm-started closed loops are not affected in practice, cold starts far from the optimum
+ *              are; a caller that needs the 1e-5 bar on every problem asks for the refusal.
  *   opts_size  sizeof(cpmpc_solver_opts) as the CALLER was compiled (0 = this header's).  Option fields are only ever
  *              appended; a caller built against an earlier header passes its shorter size and keeps the library's
- *              defaults for the fields it does not know (full_step_below was appended in round 3).  Always start from
- *              cpmpc_default_solver_opts: a zero-initialised struct is NOT the defaults.
+ *              defaults for the fields it does not know (full_step_below was appended in round 3, exit_defect_floor in
+ *              round 4).  Must be the size of the struct in some release: 8 + 8 k bytes, 104 <= size <= this header's.
+ *              Always start from cpmpc_default_solver_opts: a zero-initialised struct is NOT the defaults.
+ *              The positional constructors (cpmpc_create, cpmpc_create_model, cpmpc_sharded_create) cannot be told the
+ *              caller's size: they read CPMPC_SOLVER_OPTS_SIZE_POSITIONAL bytes -- the struct as it was when they were
+ *              frozen, i.e. up to and including full_step_below -- and take the library's defaults for everything
+ *              appended since (exit_defect_floor); newer options are set through cpmpc_create_ex.
  *   flags      CPMPC_CREATE_REFINE_QP / CPMPC_CREATE_NO_REFINE_QP: force on / off one step of iterative refinement of the
  *              whole QP solution in the fused CPMPC_F64 kernels -- residuals evaluated in the original data (terminal rows
  *              through the recovered states, stationarity through the adjoint), solved again with the factors at hand.
@@ -161,9 +170,10 @@ void cpmpc_destroy(cpmpc_solver* s);
  *                 with mu_b > 0: a slope of 1e5..1e6 1/s against a stability limit of 280 1/s at 10 ms; |Phi| reaches
  *                 1e4 per interval, the terminal system's condition 1e18): 281 of 923 648 lanes, 72 with it.
  *              Both pipelines; ignored by CPMPC_F32 handles.  cpmpc_refines_qp() tells what a handle does. */
-#define CPMPC_CREATE_ALLOW_LONG_HORIZON 1u
+#define CPMPC_CREATE_ALLOW_LONG_HORIZON 1u /* accepted; silences the long-horizon warning */
 #define CPMPC_CREATE_REFINE_QP 2u
 #define CPMPC_CREATE_NO_REFINE_QP 4u
+#define CPMPC_CREATE_STRICT_HORIZON 8u
 typedef struct cpmpc_create_info {
   uint32_t struct_size; /* = sizeof(cpmpc_create_info) */
   uint32_t flags;
@@ -177,6 +187,8 @@ typedef struct cpmpc_create_info {
   uint64_t opts_size;
 } cpmpc_create_info;
 int cpmpc_create_ex(const cpmpc_create_info* info, cpmpc_solver** out);
+/* bytes of cpmpc_solver_opts the positional constructors read (the struct through full_step_below) */
+#define CPMPC_SOLVER_OPTS_SIZE_POSITIONAL 128u
 int cpmpc_refines_qp(const cpmpc_solver* s); /* 1: this handle's kernels refine the QP solution (CPMPC_CREATE_REFINE_QP) */
 /* seconds: the longest horizon held to 1e-5 of the CPU check on every problem (1.0) */
 double cpmpc_max_parity_horizon(void);
@@ -205,7 +217,10 @@ typedef struct cpmpc_step_outputs {
   int32_t* status;     /* [B]        solver_outputs.termination_state */
   int32_t* iterations; /* [B]        QP solves performed */
   int32_t* ls_evals;   /* [B]        merit evaluations performed */
-  void* final_cost;    /* [B]        1/2 |r|^2 at the returned solution's last evaluation */
+  void* final_cost;    /* [B]        1/2 |r|^2 at the returned solution's last evaluation.  A problem that leaves with
+                        *            SATISFIED_FIRST_ORDER_TOL after a tiny undamped step took that step without a merit
+                        *            evaluation: its final_cost / final_eq_l1 are those of the iterate the
+                        *            step was computed from, one (tiny: |dz|_inf <= full_step_below) step behind u / solution */
   void* final_eq_l1;   /* [B]        |c|_1 there */
   void* guess;         /* [dim][B]   the initial guess handed to the solver */
   void* solution;      /* [dim][B]   the solution z = solver_->variables() (optimization.cc:85), MapKey order: what the
@@ -437,13 +452,19 @@ int cpmpc_set_compaction(cpmpc_solver* s, int first_iterations, int next_iterati
 /* Without an explicit cpmpc_set_compaction the stages are planned per step from how many iterations the problems of the
  * most recent FINISHED step needed (a histogram finalize leaves in host-mapped memory; read without synchronisation):
  * a settled closed loop, where every controller stops after one iteration, runs two launches instead of seven; a batch
- * whose iteration counts spread gets a cut wherever enough problems have stopped to pay for a compaction.  Speed only.
+ * whose iteration counts spread gets a cut wherever enough problems have stopped to pay for a compaction.  Speed only:
+ * results never depend on the plan, but the SEQUENCE OF LAUNCHES of a default-staged step does depend on unsynchronised
+ * timing (which earlier step's counts have reached host memory), so kernel counts in a trace differ from run to run, and
+ * a HIP-graph capture bakes in the plan of the moment and the step's stamp -- a tick captured during a transient replays
+ * its seven launches for ever, one captured when settled is bound by its stragglers after a disturbance.  Before capturing
+ * a graph, or for reproducible traces, fix the pattern with cpmpc_set_compaction.  max_iterations above 15 always takes
+ * the fixed pattern (the histogram has 16 bins, the last one standing for "ran to the cap").
  * This reads back the plan of the last step: bounds[0] = 0 < ... < bounds[n] = max_iterations, returns n (the number of
  * launches of the fused kernel), -1 on a bad argument. */
 int cpmpc_get_stage_plan(const cpmpc_solver* s, int32_t* bounds, int capacity);
 /* The planner alone (no device, no handle; for tests and tools): hist[16], hist[k] = problems that ran k iterations (the
  * last bin collects every larger count), for a batch of B problems with `intervals` = S - 1 shooting intervals.  Writes
- * bounds[0 .. n], returns n; -1 on a bad argument (max_iterations must be 1 .. 16, capacity >= max_iterations + 1). */
+ * bounds[0 .. n], returns n; -1 on a bad argument (max_iterations must be 1 .. 15, capacity >= max_iterations + 1). */
 int cpmpc_plan_stages_from_histogram(const int64_t* hist, int64_t B, int max_iterations, int intervals, int dtype,
                                      int window_length, int32_t* bounds, int capacity);
 int cpmpc_get_pipeline(const cpmpc_solver* s); /* the one a step will actually use: SPLIT or FUSED */

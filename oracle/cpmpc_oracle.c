@@ -23,6 +23,12 @@
 #define ORC_EPS DBL_EPSILON
 #endif
 
+/* the type the dense KKT solve is carried in: the arithmetic's own, except in the single-precision twin
+ * (cpmpc_oracle_f32.c), which keeps it in double like the float kernels keep their terminal system (csrc/wide.hpp) */
+#ifndef ORC_WIDE
+#define ORC_WIDE double
+#endif
+
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
 #endif
@@ -706,19 +712,20 @@ void orc_retract_model(int model, const orc_opt_params* p, const orc_solver_opts
 /* ------------------------------------------------------------------------------------------- */
 
 /* Dense LU with partial pivoting; solves K x = b in place (b -> x).  Returns nonzero if singular. */
-static int lu_solve(int n, double* K, double* b) {
-  double kmax = 0.0;
+static int lu_solve(int n, ORC_WIDE* K, ORC_WIDE* b) {
+#define ORC_WABS(v) ((v) < 0 ? -(v) : (v))
+  ORC_WIDE kmax = 0;
   for (int i = 0; i < n * n; ++i) {
-    const double a = fabs(K[i]);
+    const ORC_WIDE a = ORC_WABS(K[i]);
     if (a > kmax) kmax = a;
   }
-  if (!(kmax > 0.0) || !isfinite(kmax)) return 1;
-  const double tiny = 0.0; /* only an exactly singular or non-finite pivot is a failure */
+  if (!(kmax > 0) || !isfinite(kmax)) return 1;
+  const ORC_WIDE tiny = 0; /* only an exactly singular or non-finite pivot is a failure */
   for (int col = 0; col < n; ++col) {
     int piv = col;
-    double best = fabs(K[col * n + col]);
+    ORC_WIDE best = ORC_WABS(K[col * n + col]);
     for (int r = col + 1; r < n; ++r) {
-      const double a = fabs(K[r * n + col]);
+      const ORC_WIDE a = ORC_WABS(K[r * n + col]);
       if (a > best) {
         best = a;
         piv = r;
@@ -727,27 +734,28 @@ static int lu_solve(int n, double* K, double* b) {
     if (!(best > tiny)) return 1;
     if (piv != col) {
       for (int j = 0; j < n; ++j) {
-        const double t = K[col * n + j];
+        const ORC_WIDE t = K[col * n + j];
         K[col * n + j] = K[piv * n + j];
         K[piv * n + j] = t;
       }
-      const double t = b[col];
+      const ORC_WIDE t = b[col];
       b[col] = b[piv];
       b[piv] = t;
     }
-    const double inv = 1.0 / K[col * n + col];
+    const ORC_WIDE inv = 1 / K[col * n + col];
     for (int r = col + 1; r < n; ++r) {
-      const double f = K[r * n + col] * inv;
-      if (f == 0.0) continue;
+      const ORC_WIDE f = K[r * n + col] * inv;
+      if (f == 0) continue;
       for (int j = col + 1; j < n; ++j) K[r * n + j] -= f * K[col * n + j];
       b[r] -= f * b[col];
     }
   }
   for (int r = n - 1; r >= 0; --r) {
-    double acc = b[r];
+    ORC_WIDE acc = b[r];
     for (int j = r + 1; j < n; ++j) acc -= K[r * n + j] * b[j];
     b[r] = acc / K[r * n + r];
   }
+#undef ORC_WABS
   return 0;
 }
 
@@ -763,21 +771,21 @@ static int lu_solve(int n, double* K, double* b) {
 int orc_qp_solve(int dim, int n_eq, int n_cost, int n_u, const double* J_cost, const double* r_cost,
                  const double* A_eq, const double* c_eq, double lambda, double* dz) {
   const int n = dim + n_eq;
-  double* K = (double*)calloc((size_t)n * (size_t)n, sizeof(double));
-  double* b = (double*)calloc((size_t)n, sizeof(double));
+  ORC_WIDE* K = (ORC_WIDE*)calloc((size_t)n * (size_t)n, sizeof(ORC_WIDE));
+  ORC_WIDE* b = (ORC_WIDE*)calloc((size_t)n, sizeof(ORC_WIDE));
   for (int r = 0; r < n_cost; ++r) {
     const double* row = J_cost + (size_t)r * dim;
     for (int i = 0; i < dim; ++i) {
-      const double a = row[i];
-      if (a == 0.0) continue;
-      b[i] -= a * r_cost[r];
-      for (int j = 0; j < dim; ++j) K[(size_t)i * n + j] += a * row[j];
+      const ORC_WIDE a = row[i];
+      if (a == 0) continue;
+      b[i] -= a * (ORC_WIDE)r_cost[r];
+      for (int j = 0; j < dim; ++j) K[(size_t)i * n + j] += a * (ORC_WIDE)row[j]; /* (products of the arithmetic's values, summed in ORC_WIDE) */
     }
   }
   for (int k = dim - n_u; k < dim; ++k) K[(size_t)k * n + k] += lambda;
   for (int r = 0; r < n_eq; ++r) {
     for (int j = 0; j < dim; ++j) {
-      const double a = A_eq[(size_t)r * dim + j];
+      const ORC_WIDE a = A_eq[(size_t)r * dim + j];
       K[(size_t)(dim + r) * n + j] = a;
       K[(size_t)j * n + dim + r] = a;
     }
@@ -786,7 +794,7 @@ int orc_qp_solve(int dim, int n_eq, int n_cost, int n_u, const double* J_cost, c
   const int bad = lu_solve(n, K, b);
   if (!bad) {
     for (int i = 0; i < dim; ++i) {
-      dz[i] = b[i];
+      dz[i] = (double)b[i];
       if (!isfinite(b[i])) {
         free(K);
         free(b);
@@ -888,8 +896,11 @@ static int solve(const orc_model* m, const orc_opt_params* p, const orc_solver_o
     /* first-order test: the step is still tried (and kept if it passes Armijo) before exiting.  Equality residuals at
      * the rounding floor of their own evaluation -- the shooting defects are differences of states after state_spacing
      * RK4 steps -- count as zero here: no iteration can remove them, and in single precision mu |c|_1 at that floor
-     * (1e-6 .. 1e-4) would keep a converged controller iterating on noise for ever (round 4; in double the floor is
-     * 3e-14 and changes nothing).  The merit and the Armijo test use the residuals as they are. */
+     * (1e-6 .. 1e-4) would keep a converged controller iterating on noise for ever (round 4).  A SINGLE-PRECISION rule
+     * (round 5): in double the floor would be 3e-14 -- it could move a decision only where |D| is within mu x 3e-14 of the
+     * tolerance -- and the double kernels never carried the test, so the double builds of this file do not apply it either:
+     * one exit rule in the parity dtype.  It is live in cpmpc_oracle_f32.c (ORC_EPS = FLT_EPSILON).  The merit and the
+     * Armijo test use the residuals as they are. */
     /* the size of the states, taken at the terminal node (target and distance to it) times the number of intervals: the
      * nodes of a plan that is near its targets are all about that large, and a plan that is not has residuals far above
      * any rounding anyway */
@@ -905,7 +916,7 @@ static int solve(const orc_model* m, const orc_opt_params* p, const orc_solver_o
       }
       x_l1 *= (double)(S_ - 1);
     }
-    const double cn_floor = o->exit_defect_floor * (double)p->state_spacing * (double)ORC_EPS * x_l1;
+    const double cn_floor = ((double)ORC_EPS > (double)1e-10) ? o->exit_defect_floor * (double)p->state_spacing * (double)ORC_EPS * x_l1 : (double)0.0;
     const double D_exit = gd - mu * (cn > cn_floor ? cn : 0.0);
     const int first_order = fabs(D_exit) < p->absolute_first_derivative_tol;
 
@@ -933,8 +944,12 @@ static int solve(const orc_model* m, const orc_opt_params* p, const orc_solver_o
     if (first_order && tiny) {
       /* Converged (round 4): the first-order test holds and the undamped QP step is tiny in every component.  The full
        * step is taken and the iteration ends, WITHOUT evaluating the merit at the new point: nothing depends on that
-       * value any more (the tiny rule accepts any finite merit), and it is a whole rollout -- a quarter of the work of a
-       * settled controller's tick.  The reported cost and residual are those of the iterate the step was computed from. */
+       * value any more, and it is a whole rollout -- a quarter of the work of a settled controller's tick.  The reported
+       * cost and residual are those of the iterate the step was computed from.  The committed iterate is finite without a
+       * check of its own: z is (f and |c|_1 were tested above and every variable enters a residual), |dz|_inf <= full_step_below
+       * is (`tiny` is false for a NaN or infinite component), and the retraction only wraps and clamps; a problem whose
+       * data are not finite never gets here -- it left with NON_FINITE at the linearisation
+       * (tests/test_gpu_round5.py::test_poisoned_settled_controllers...). */
       retract(m, p, o, z, dz, 1.0, zt);
       memcpy(z, zt, sizeof(double) * (size_t)dim);
       lambda *= o->lambda_scale_down;

@@ -12,6 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libcpmpc_oracle.so")
 _LIB_LD_PATH = os.path.join(_HERE, "libcpmpc_oracle_ld.so")
+_LIB_F32_PATH = os.path.join(_HERE, "libcpmpc_oracle_f32.so")
 
 
 def build(force=False):
@@ -35,6 +36,17 @@ def build_ld(force=False):
     subprocess.check_call(["make", "-C", _HERE, "-B", "libcpmpc_oracle_ld.so"], stdout=subprocess.DEVNULL,
                           stderr=subprocess.DEVNULL)
     return _LIB_LD_PATH
+
+
+def build_f32(force=False):
+    """Compile the single-precision twin of the same restatement (cpmpc_oracle_f32.c: float arithmetic, KKT solve in double)."""
+    srcs = [os.path.join(_HERE, f) for f in ("cpmpc_oracle_f32.c", "cpmpc_oracle.c", "cpmpc_oracle.h")]
+    if (not force and os.path.exists(_LIB_F32_PATH)
+            and os.path.getmtime(_LIB_F32_PATH) >= max(os.path.getmtime(f) for f in srcs)):
+        return _LIB_F32_PATH
+    subprocess.check_call(["make", "-C", _HERE, "-B", "libcpmpc_oracle_f32.so"], stdout=subprocess.DEVNULL,
+                          stderr=subprocess.DEVNULL)
+    return _LIB_F32_PATH
 
 
 class OptParams(C.Structure):
@@ -106,6 +118,8 @@ TERM_NAMES = {
     8: "NON_FINITE",
 }
 TERM = {v: k for k, v in TERM_NAMES.items()}
+for _k, _v in TERM.items():
+    globals()["TERM_" + _k] = _v
 
 _dp = C.POINTER(C.c_double)
 _lib = None
@@ -198,6 +212,26 @@ def lib_ld():
         L.orcld_step_batch_cold_d.restype = C.c_int
         _lib_ld = L
     return _lib_ld
+
+
+_lib_f32 = None
+
+
+def lib_f32():
+    global _lib_f32
+    if _lib_f32 is None:
+        build_f32()
+        L = C.CDLL(_LIB_F32_PATH)
+        ip = C.POINTER(C.c_int32)
+        bp = C.POINTER(C.c_int8)
+        L.orcf_step_batch_cold_d.argtypes = [C.c_int, C.POINTER(OptParams), C.POINTER(SolverOpts), _dp, C.c_double,
+                                             C.c_int64, _dp, _dp, ip, ip, ip, _dp, C.c_int]
+        L.orcf_step_batch_cold_d.restype = C.c_int
+        L.orcf_closed_loop_d.argtypes = [C.c_int, C.POINTER(OptParams), C.POINTER(SolverOpts), _dp, C.c_double, C.c_int64,
+                                         _dp, C.c_int, bp, bp, _dp, C.c_int]
+        L.orcf_closed_loop_d.restype = C.c_int
+        _lib_f32 = L
+    return _lib_f32
 
 
 def default_opt_params(**overrides):
@@ -510,3 +544,43 @@ def step_batch_cold_ld(p, dyn, set_point, x0_soa, opts=None, num_threads=0, mode
                                      float(set_point), B, _ptr(x0), _ptr(u), status.ctypes.data_as(ip),
                                      iters.ctypes.data_as(ip), evals.ctypes.data_as(ip), _ptr(eq), int(num_threads))
     return u, status, iters, evals, eq
+
+
+def step_batch_cold_f32(p, dyn, set_point, x0_soa, opts=None, num_threads=0, model="single"):
+    """The same cold-start re-plan in SINGLE precision (oracle/cpmpc_oracle_f32.c: float arithmetic, the KKT solve in
+    double as the float kernels keep their terminal system): the checker at the CPMPC_F32 kernels' precision.  Returns
+    (u [N,B] as double, status, iters, line-search evaluations, final |c|_1)."""
+    m = MODELS[model]
+    nx = model_nx(m)
+    x0 = np.ascontiguousarray(x0_soa, dtype=np.float64)
+    assert x0.ndim == 2 and x0.shape[0] == nx
+    B, N = x0.shape[1], int(p.window_length)
+    dyn = _vec(dyn, model_np(m))
+    u = np.zeros((N, B))
+    status, iters, evals = (np.zeros(B, dtype=np.int32) for _ in range(3))
+    eq = np.zeros(B)
+    ip = C.POINTER(C.c_int32)
+    lib_f32().orcf_step_batch_cold_d(m, C.byref(p), C.byref(opts) if opts is not None else None, _ptr(dyn),
+                                     float(set_point), B, _ptr(x0), _ptr(u), status.ctypes.data_as(ip),
+                                     iters.ctypes.data_as(ip), evals.ctypes.data_as(ip), _ptr(eq), int(num_threads))
+    return u, status, iters, evals, eq
+
+
+def closed_loop_f32(p, dyn, set_point, x0_soa, ticks, opts=None, num_threads=0, model="single"):
+    """B controllers in closed loop in SINGLE precision (warm-started Optimization::Step -> u_0 -> Simulator::Step per tick,
+    optimization_test.cc:39-61 per controller).  Returns (status [ticks,B] int8, iterations [ticks,B] int8, final states
+    [nx,B], threads used)."""
+    m = MODELS[model]
+    nx = model_nx(m)
+    x0 = np.ascontiguousarray(x0_soa, dtype=np.float64)
+    assert x0.ndim == 2 and x0.shape[0] == nx
+    B = x0.shape[1]
+    dyn = _vec(dyn, model_np(m))
+    status = np.zeros((ticks, B), dtype=np.int8)
+    iters = np.zeros((ticks, B), dtype=np.int8)
+    xf = np.zeros((nx, B))
+    bp = C.POINTER(C.c_int8)
+    used = lib_f32().orcf_closed_loop_d(m, C.byref(p), C.byref(opts) if opts is not None else None, _ptr(dyn),
+                                        float(set_point), B, _ptr(x0), int(ticks), status.ctypes.data_as(bp),
+                                        iters.ctypes.data_as(bp), _ptr(xf), int(num_threads))
+    return status, iters, xf, used

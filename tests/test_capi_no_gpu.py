@@ -136,22 +136,26 @@ def test_fails_loudly_without_a_gpu(lib, pkg):
         pkg.capi.check(rc)
 
 
-def test_long_horizons_are_refused_unless_asked_for(lib, pkg):
-    """window_length * control_dt beyond cpmpc_max_parity_horizon() (1.0 s) is CPMPC_ERR_UNSUPPORTED from every positional
-    constructor, with the flag that lifts it named in the message; cpmpc_create_ex with the flag gets as far as the
-    device check.  The versioned structs reject a wrong struct_size / opts_size.  (No device is needed for any of it.)"""
+def test_long_horizons_are_accepted_and_refused_only_when_asked(lib, pkg, capfd):
+    """The reference's constructor accepts any horizon (optimization.cc:13-22), so every constructor of the drop-in does
+    (ADVICE r4): window_length * control_dt beyond cpmpc_max_parity_horizon() (1.0 s) gets as far as the device check from
+    the positional entry points, with one warning per process on stderr; CPMPC_CREATE_STRICT_HORIZON through cpmpc_create_ex
+    is CPMPC_ERR_UNSUPPORTED with the reason in the message.  The versioned structs reject a wrong struct_size / opts_size.
+    (No device is needed for any of it.)"""
     assert lib.cpmpc_max_parity_horizon() == pytest.approx(1.0)
     h = C.c_void_p()
+    past = (pkg.capi.OK, pkg.capi.ERR_NO_DEVICE)
     for over in (dict(window_length=160), dict(window_length=120, state_spacing=12), dict(control_dt=0.05)):
         p = pkg.capi.default_params(**over)
-        assert lib.cpmpc_create(C.byref(p), None, pkg.capi.F64, 8, 0, C.byref(h)) == pkg.capi.ERR_UNSUPPORTED, over
-        assert b"CPMPC_CREATE_ALLOW_LONG_HORIZON" in lib.cpmpc_last_error()
-        assert lib.cpmpc_sharded_create(C.byref(p), None, pkg.capi.F64, 8, None, 0, C.byref(h)) in (
-            pkg.capi.ERR_UNSUPPORTED, pkg.capi.ERR_NO_DEVICE)
-    ok = pkg.capi.default_params(window_length=100)
-    assert lib.cpmpc_create(C.byref(ok), None, pkg.capi.F64, 8, 0, C.byref(h)) in (pkg.capi.OK, pkg.capi.ERR_NO_DEVICE)
-    if h.value:
-        lib.cpmpc_destroy(h)
+        assert lib.cpmpc_create(C.byref(p), None, pkg.capi.F64, 8, 0, C.byref(h)) in past, over
+        if h.value:
+            lib.cpmpc_destroy(h)
+        hs = C.c_void_p()
+        assert lib.cpmpc_sharded_create(C.byref(p), None, pkg.capi.F64, 8, None, 0, C.byref(hs)) in past
+        if hs.value:
+            lib.cpmpc_sharded_destroy(hs)
+    err = capfd.readouterr().err
+    assert err.count("cpmpc_max_parity_horizon") <= 1   # said once per process (another test may have been first)
     p = pkg.capi.default_params(window_length=160)
 
     def info(**kw):
@@ -161,9 +165,15 @@ def test_long_horizons_are_refused_unless_asked_for(lib, pkg):
             setattr(i, k, v)
         return i
     h = C.c_void_p()
-    assert lib.cpmpc_create_ex(C.byref(info()), C.byref(h)) == pkg.capi.ERR_UNSUPPORTED
-    rc = lib.cpmpc_create_ex(C.byref(info(flags=pkg.capi.CREATE_ALLOW_LONG_HORIZON)), C.byref(h))
-    assert rc in (pkg.capi.OK, pkg.capi.ERR_NO_DEVICE)   # past the horizon check
+    assert lib.cpmpc_create_ex(C.byref(info(flags=pkg.capi.CREATE_STRICT_HORIZON)), C.byref(h)) == pkg.capi.ERR_UNSUPPORTED
+    assert b"CPMPC_CREATE_STRICT_HORIZON" in lib.cpmpc_last_error()
+    for fl in (0, pkg.capi.CREATE_ALLOW_LONG_HORIZON):
+        rc = lib.cpmpc_create_ex(C.byref(info(flags=fl)), C.byref(h))
+        assert rc in past   # past the horizon check
+        if h.value:
+            lib.cpmpc_destroy(h)
+    p = pkg.capi.default_params(window_length=100)   # at the bound: strict accepts
+    assert lib.cpmpc_create_ex(C.byref(info(flags=pkg.capi.CREATE_STRICT_HORIZON)), C.byref(h)) in past
     if h.value:
         lib.cpmpc_destroy(h)
     assert lib.cpmpc_create_ex(C.byref(info(struct_size=12)), C.byref(h)) == pkg.capi.ERR_INVALID_ARG
@@ -171,6 +181,39 @@ def test_long_horizons_are_refused_unless_asked_for(lib, pkg):
     o = pkg.capi.default_solver_opts()
     assert lib.cpmpc_create_ex(C.byref(info(flags=1, opts=C.pointer(o), opts_size=C.sizeof(o) + 8)),
                                C.byref(h)) == pkg.capi.ERR_INVALID_ARG
+    # a size that is nobody's struct: it splits a double, or is shorter than the first release's
+    for bad in (4, 100, C.sizeof(o) - 4):
+        assert lib.cpmpc_create_ex(C.byref(info(opts=C.pointer(o), opts_size=bad)), C.byref(h)) == pkg.capi.ERR_INVALID_ARG, bad
+    for good in (104, pkg.capi.SOLVER_OPTS_SIZE_POSITIONAL, C.sizeof(o)):
+        rc = lib.cpmpc_create_ex(C.byref(info(opts=C.pointer(o), opts_size=good)), C.byref(h))
+        assert rc in past, good
+        if h.value:
+            lib.cpmpc_destroy(h)
+
+
+def test_positional_constructors_read_the_frozen_options_struct(lib, pkg):
+    """cpmpc_create / cpmpc_create_model / cpmpc_sharded_create cannot be told the caller's sizeof(cpmpc_solver_opts): they
+    read the struct as it was when they were frozen (through full_step_below, CPMPC_SOLVER_OPTS_SIZE_POSITIONAL bytes) and
+    never the fields appended since -- a caller compiled against that header is not read past its struct.
+    Here: a buffer of exactly that many bytes followed by a poisoned double (NaN would be rejected as exit_defect_floor if
+    it were read) is accepted."""
+    o = pkg.capi.default_solver_opts()
+    n = pkg.capi.SOLVER_OPTS_SIZE_POSITIONAL
+    assert n == pkg.capi.SolverOpts.exit_defect_floor.offset   # the first appended field starts where the frozen struct ends
+    buf = (C.c_ubyte * (n + 8))()
+    C.memmove(buf, C.byref(o), n)
+    C.memmove(C.byref(buf, n), C.byref(C.c_double(float("nan"))), 8)
+    p = pkg.capi.default_params()
+    h = C.c_void_p()
+    rc = lib.cpmpc_create(C.byref(p), C.cast(buf, C.POINTER(pkg.capi.SolverOpts)), pkg.capi.F64, 8, 0, C.byref(h))
+    assert rc in (pkg.capi.OK, pkg.capi.ERR_NO_DEVICE), lib.cpmpc_last_error()
+    if h.value:
+        lib.cpmpc_destroy(h)
+    # through cpmpc_create_ex with the full size the same poison IS read, and refused
+    info = pkg.capi.CreateInfo(struct_size=C.sizeof(pkg.capi.CreateInfo), flags=0, dtype=pkg.capi.F64, model=0, device=0,
+                               reserved=0, max_batch=8, params=C.pointer(p),
+                               opts=C.cast(buf, C.POINTER(pkg.capi.SolverOpts)), opts_size=n + 8)
+    assert lib.cpmpc_create_ex(C.byref(info), C.byref(h)) == pkg.capi.ERR_INVALID_ARG
 
 
 def test_product_does_not_import_the_oracle():
@@ -190,7 +233,12 @@ def test_rule_thresholds_are_validated(lib, pkg):
         for bad in (-1.0, float("nan"), float("inf")):
             o = pkg.capi.default_solver_opts(**{field: bad})
             h = C.c_void_p()
-            assert lib.cpmpc_create(C.byref(p), C.byref(o), pkg.capi.F64, 8, 0, C.byref(h)) == pkg.capi.ERR_INVALID_ARG, (field, bad)
+            info = pkg.capi.CreateInfo(struct_size=C.sizeof(pkg.capi.CreateInfo), flags=0, dtype=pkg.capi.F64, model=0,
+                                       device=0, reserved=0, max_batch=8, params=C.pointer(p), opts=C.pointer(o),
+                                       opts_size=C.sizeof(o))
+            assert lib.cpmpc_create_ex(C.byref(info), C.byref(h)) == pkg.capi.ERR_INVALID_ARG, (field, bad)
+            if field == "full_step_below":   # inside the struct the positional constructors read
+                assert lib.cpmpc_create(C.byref(p), C.byref(o), pkg.capi.F64, 8, 0, C.byref(h)) == pkg.capi.ERR_INVALID_ARG
 
 
 def _plan(lib, hist, B=262144, T=8, intervals=4, dtype=1, window=40):

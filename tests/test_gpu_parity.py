@@ -647,8 +647,9 @@ def test_profiling_counts_launches(pkg):
                                   dict(window_length=80, state_spacing=5, max_iterations=3)])
 def test_long_horizons_fused(pkg, orc, over):
     """Horizons of 80 and 160 steps: 8 and 16 lanes per problem in the fused kernel (generic group traffic).
-    N = 80 (0.8 s; the library accepts up to 1.0 s without being asked, cpmpc_max_parity_horizon): EVERY lane of both
-    pipelines within 1e-5 of the oracle.  N = 160 (1.6 s) must be asked for (CPMPC_CREATE_ALLOW_LONG_HORIZON):
+    N = 80 (0.8 s; within cpmpc_max_parity_horizon = 1.0 s): EVERY lane of both
+    pipelines within 1e-5 of the oracle.  N = 160 (1.6 s) is solved like the reference would (refused only with
+    CPMPC_CREATE_STRICT_HORIZON):
     eliminating the states through 16 intervals of an unstable plant loses about three digits per QP against the
     oracle's full-space KKT solve, and at batch scale 0.5 % of cold starts end beyond 1e-5 (profiles/r04_parity_sweep.json;
     neither wider accumulation of the terminal system nor more refinement passes change that); on
@@ -657,12 +658,11 @@ def test_long_horizons_fused(pkg, orc, over):
     x0 = random_states(rng, 96)
     x0[1, ::2] = np.pi / 2 + rng.uniform(-0.3, 0.3, 48)
     long_h = over["window_length"] > 100
-    if long_h:  # refused unless asked for, with the reason in the message
+    if long_h:  # refused when the caller asks for the 1e-5 bar on every problem, with the reason in the message
         with pytest.raises(pkg.CpmpcError) as exc:
-            pkg.BatchOptimization(pkg.default_params(**over), max_batch=96, dtype=torch.float64, device=0)
-        assert exc.value.code == pkg.capi.ERR_UNSUPPORTED and "ALLOW_LONG_HORIZON" in str(exc.value)
-    opt = pkg.BatchOptimization(pkg.default_params(**over), max_batch=96, dtype=torch.float64, device=0,
-                                allow_long_horizon=long_h)
+            pkg.BatchOptimization(pkg.default_params(**over), max_batch=96, dtype=torch.float64, device=0, strict_horizon=True)
+        assert exc.value.code == pkg.capi.ERR_UNSUPPORTED and "STRICT_HORIZON" in str(exc.value)
+    opt = pkg.BatchOptimization(pkg.default_params(**over), max_batch=96, dtype=torch.float64, device=0)
     assert opt.pipeline() == "fused"
     out = opt.step(T(x0), DYN_UI, 0.0)
     u_cpu, _, st_cpu, it_cpu, _ = orc.step_batch_cold(orc.default_opt_params(**over), DYN_UI, 0.0, x0)

@@ -226,7 +226,10 @@ def test_fp32_settled_controllers_do_not_iterate_on_rounding(pkg):
     of the rollout count as zero.  Single precision, the reference's tolerances (absolute_first_derivative_tol = 1e-6),
     controllers settled at the set-point: with the floor (default) most leave after one iteration, without it (0) none can
     -- mu |c|_1 of the rounding alone is 1e-6 .. 1e-4 -- and they iterate until the relative test happens to pass.  The
-    poles stand equally well either way, and in double precision the floor changes nothing at all (bit for bit)."""
+    poles stand equally well either way.  The rule is a SINGLE-PRECISION rule (round 5: one exit rule in the parity dtype):
+    CPMPC_F64 handles ignore the option (include/cpmpc.h) and the double CPU check does not apply it either -- the last two
+    runs document the first half (the same kernels run whatever the option says), tests/test_oracle_f32.py holds the second
+    and checks the branch itself against the single-precision build of the CPU check."""
     B, ticks = 8192, 260
     rng = np.random.default_rng(23)
     xs = np.stack([rng.uniform(-0.05, 0.05, B), np.pi / 2 + rng.uniform(-0.05, 0.05, B), rng.uniform(-0.1, 0.1, B), rng.uniform(-0.1, 0.1, B)])
