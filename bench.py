@@ -59,6 +59,19 @@ FLOPS_PER_LAUNCH_UNIT = {
     # one launch = all SQP iterations; multiplied by --iters below
     "fused_sqp_kernel": FLOPS_LINEARIZE + FLOPS_QP + FLOPS_MERIT,
 }
+# The same tally for the cart + double pendulum (BASELINE configs[4], NX = 6), derived the way SURVEY 8(d) derives the
+# 4-state one: one evaluation of the dynamics with its Jacobians 249 flops (generated terms 74, 3 x 3
+# LDL^T 19, eight solves of 15, right-hand sides 36) + 2 sincos; RK4 with sensitivities as integration.hpp:13-49 does it
+# for D = 6 (four evaluations, three dense 6 x 6 products and 6 x 6 . 6 x 1, the sums) 2 916; the chain rule of
+# optimization.cc:145-154 per step 396 + 66; a Jacobian-free step 4 x 79 + 78 = 394; the structured QP scaled from the
+# 4-state 30 k by the mean of (6/4) and (6/4)^2.
+FLOPS_NX6 = {"linearize": 40 * (2916 + 462), "merit": 40 * 394, "qp": 56_000}
+FLOPS_PER_LAUNCH_UNIT_NX6 = {
+    "linearize_kernel": FLOPS_NX6["linearize"], "qp_ls_kernel": FLOPS_NX6["qp"] + FLOPS_NX6["merit"],
+    "prepare_kernel": FLOPS_NX6["merit"], "finalize_kernel": FLOPS_NX6["merit"],
+    "fused_sqp_kernel": FLOPS_NX6["linearize"] + FLOPS_NX6["qp"] + FLOPS_NX6["merit"],
+}
+DYN_DOUBLE = [1.0, 0.1, 0.1, 0.25, 0.2, 9.81]   # m_b, m_1, m_2, l_1, l_2, g (symbolic/dynamics_double.py:13-22; the tests' values)
 PEAK_VALU_TFLOPS = {"f32": 157.3, "f64": 78.6}  # MI355X_MICROARCH.md (vector peak); f64 = public spec
 PEAK_HBM_GBPS = 8000.0
 SEED = 1000
@@ -140,6 +153,7 @@ def launch_ranks(n, argv, n_devices=None, script=None, timeout=None):
     other ranks write to stderr.  All ranks are polled together: the first one to exit non-zero ends the run at once --
     the others (which would otherwise sit in a collective until its timeout) are killed and that exit code is returned.
     `timeout` (default CPMPC_BENCH_TIMEOUT or 3600 s) bounds the whole run the same way.  Never restarts anything."""
+    import tempfile
     import threading
     share = os.environ.get("CPMPC_BENCH_SHARE_DEVICE", "0") == "1"
     if n_devices is None:
@@ -152,10 +166,15 @@ def launch_ranks(n, argv, n_devices=None, script=None, timeout=None):
     chunks = []
     reader = None
     rc = 0
+    failed_rank = None
+    # every rank's stderr (and the stdout of ranks > 0) goes to a file of its own: relayed to this process's stderr when the
+    # run ends, and on a failure the failing rank's LAST 40 LINES are printed under the launcher's verdict -- on an 8-GPU
+    # node the first contact with RCCL fails in one rank, and its message must not be lost among seven others' 
+    logdir = tempfile.mkdtemp(prefix="cpmpc_bench_ranks_")
+    logs = [open(os.path.join(logdir, "rank%d.stderr" % r), "w+") for r in range(n)]
     try:
         for r, e in enumerate(envs):
-            procs.append(subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if r == 0 else sys.stderr,
-                                          stderr=sys.stderr, text=True))
+            procs.append(subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if r == 0 else logs[r], stderr=logs[r], text=True))
         reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
         reader.start()
         deadline = time.monotonic() + timeout
@@ -164,8 +183,8 @@ def launch_ranks(n, argv, n_devices=None, script=None, timeout=None):
             bad = [c for c in codes if c not in (None, 0)]
             if bad:
                 rc = bad[0]
-                sys.stderr.write("bench.py launcher: rank %d exited with code %d; stopping the other ranks\n"
-                                 % (codes.index(bad[0]), bad[0]))
+                failed_rank = codes.index(bad[0])
+                sys.stderr.write("bench.py launcher: rank %d exited with code %d; stopping the other ranks\n" % (failed_rank, bad[0]))
                 break
             if all(c == 0 for c in codes):
                 break
@@ -185,6 +204,31 @@ def launch_ranks(n, argv, n_devices=None, script=None, timeout=None):
                 pass
         if reader is not None:
             reader.join(timeout=30)
+        texts = []
+        for r, fh in enumerate(logs):
+            try:
+                fh.flush()
+                fh.seek(0)
+                texts.append(fh.read())
+            except (OSError, ValueError):
+                texts.append("")
+            fh.close()
+        for r, t in enumerate(texts):   # the ranks' own messages (device report, warnings, RCCL banner), rank by rank
+            for ln in t.splitlines():
+                sys.stderr.write("[rank %d] %s\n" % (r, ln))
+        if failed_rank is not None or rc == 124:
+            which = [failed_rank] if failed_rank is not None else list(range(n))
+            for r in which:
+                tail = texts[r].splitlines()[-40:] if r < len(texts) else []
+                sys.stderr.write("bench.py launcher: last %d stderr line(s) of rank %d:\n" % (len(tail), r))
+                for ln in tail:
+                    sys.stderr.write("    | %s\n" % ln)
+        try:
+            for r in range(n):
+                os.remove(os.path.join(logdir, "rank%d.stderr" % r))
+            os.rmdir(logdir)
+        except OSError:
+            pass
     return rc, "".join(c for c in chunks if c)
 
 
@@ -267,10 +311,12 @@ def cpu_baseline(x0_np, over, seconds_target=20.0):
                       "oracle/cpmpc_oracle.c with OpenMP (%d threads), %.1f s" % (n, int(used), dt)}, u, st, n
 
 
-def timed_region(torch, dist, sharding, opt, x0, outs, gather, steps, warmup, dev, local_rank, distributed):
-    """W untimed steps, then exactly K steps bracketed by barrier + synchronize on both sides.  Returns
+def timed_region(torch, dist, sharding, opt, x0, outs, gather, steps, warmup, dev, local_rank, distributed, preheat_s=0.0):
+    """An untimed pre-heat of `preheat_s` seconds of the same steps (the device of a fresh lease runs its first tens of
+    milliseconds 3 % slower than a warm one: the driver's 20-step run saw 117.3 M where 200 steps gave 122 M),
+    then W untimed steps, then exactly K steps bracketed by barrier + synchronize on both sides.  Returns
     (max-over-ranks seconds, this rank's own seconds up to the end of its last step and gather -- before the closing
-    barrier --, per-kernel HIP-event profile of the timed steps, outputs of the last step, its slot)."""
+    barrier --, per-kernel HIP-event profile of the timed steps, outputs of the last step, its slot, pre-heat steps run)."""
     state = {"n": 0, "slot": 0}
 
     def one_step():
@@ -294,10 +340,29 @@ def timed_region(torch, dist, sharding, opt, x0, outs, gather, steps, warmup, de
         torch.cuda.synchronize()
 
     out = None
+    n_pre = 0
+    # pending destructors run NOW, before anything that is meant to keep the device busy up to the timed steps: a collection
+    # between the warm-up and the timed region (where it sat until round 5) idles the device for tens of milliseconds, and
+    # the first ~20 steps after such a gap run 4 % slower (the collector itself is off for the whole run: run_rank)
+    gc.collect()
+    if preheat_s > 0.0:
+        # every rank runs the same number of pre-heat steps (the gather's slots advance together): rank 0's clock decides
+        # in rounds of 32 steps, the decision travels through the max-reduce the timing uses anyway
+        t_pre = time.perf_counter()
+        where = dev if dist.is_initialized() and dist.get_backend() == "nccl" else "cpu"
+        while True:
+            for _ in range(32):
+                out = one_step()
+            n_pre += 32
+            torch.cuda.synchronize()
+            more = 1.0 if time.perf_counter() - t_pre < preheat_s else 0.0
+            if distributed:
+                more = sharding.max_over_ranks(more, where)
+            if more <= 0.0 or n_pre >= 100000:
+                break
     for _ in range(warmup):
         out = one_step()
-    gc.collect()   # no destructor of an earlier leg's handle inside the timed steps (see quiesce)
-    fence()
+    fence()   # synchronize + barrier + synchronize: the only gap between the last warm-up step and the first timed one
     opt.profile_enable(True)
     opt.profile_reset()
     t0 = time.perf_counter()
@@ -312,21 +377,24 @@ def timed_region(torch, dist, sharding, opt, x0, outs, gather, steps, warmup, de
     elapsed = sharding.max_over_ranks(elapsed, dev if dist.is_initialized() and dist.get_backend() == "nccl" else "cpu")
     prof = opt.profile_read()
     opt.profile_enable(False)
-    return elapsed, own, prof, out, state["slot"]
+    return elapsed, own, prof, out, state["slot"], n_pre
 
 
-def roofline_of(prof, dtype, B, iters, steps, rate_per_gpu):
+def roofline_of(prof, dtype, B, iters, steps, rate_per_gpu, nx=4):
     """Roofline object of the dominant kernel (by HIP-event device time over the timed region)."""
     dom = max(prof, key=lambda k: prof[k][0])
     dom_ms, dom_n = prof[dom]
     avg_s = dom_ms / max(dom_n, 1) * 1e-3
-    flops_launch = FLOPS_PER_LAUNCH_UNIT[dom] * B * (iters if dom == "fused_sqp_kernel" else 1)
+    table = FLOPS_PER_LAUNCH_UNIT if nx == 4 else FLOPS_PER_LAUNCH_UNIT_NX6
+    flops_launch = table[dom] * B * (iters if dom == "fused_sqp_kernel" else 1)
     achieved_tf = flops_launch / avg_s / 1e12
     peak_tf = PEAK_VALU_TFLOPS[dtype]
     esz = 4 if dtype == "f32" else 8
-    bytes_replan = esz * ((4 + 1) + (60 + 160)) + 4   # read x0 + set-point, write z + predicted, status
+    S = 5
+    bytes_replan = esz * ((nx + 1) + (nx * S + 40 + 40 * nx)) + 4   # read x0 + set-point, write z + predicted, status
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json" if dtype == "f32" else "traffic_latest_%s.json" % dtype)
+    tpath = os.path.join(ROOT, "profiles", ("traffic_latest.json" if dtype == "f32" else "traffic_latest_%s.json" % dtype)
+                         if nx == 4 else "traffic_latest_double_%s.json" % dtype)
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
@@ -518,9 +586,18 @@ def variants(torch, pkg, args, tdt, dev, local_rank, x0, B):
     except Exception as exc:  # noqa: BLE001
         res["per_problem_params"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     try:
+        res["double_pendulum"] = double_pendulum_variant(torch, pkg, args, dev, local_rank)
+    except Exception as exc:  # noqa: BLE001
+        res["double_pendulum"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    try:
         res["shards_on_streams"] = split_streams_variant(torch, pkg, args, dev, local_rank, B)
     except Exception as exc:  # noqa: BLE001
         res["shards_on_streams"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    try:
+        quiesce(torch)
+        res["plain_sqp"] = plain_sqp_variant()
+    except Exception as exc:  # noqa: BLE001
+        res["plain_sqp"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     try:
         res["single_controller_facade"] = single_controller_latency(pkg)
     except Exception as exc:  # noqa: BLE001
@@ -593,6 +670,103 @@ def per_problem_variant(torch, pkg, args, dev, local_rank, B, lanes=4096, steps=
         rec["parity_vs_cpu_check"] = ps
         res[name] = rec
         del opt
+    return res
+
+
+def double_pendulum_variant(torch, pkg, args, dev, local_rank, B=65536, lanes=4096, steps=20):
+    """BASELINE configs[4] as a measured configuration: cart + double pendulum (6 states,
+    symbolic/dynamics_double.py:53-148), B = 65 536, N = 40, state_spacing 10, 5 SQP iterations, exits disabled, cold start
+    (zero control guess: the 10 N sinusoid throws the light poles over) from two state distributions -- the tests'
+    near-upright one (both poles within 0.15 rad) and poles anywhere within 0.5 rad of upright -- in both dtypes:
+    re-plans/s (HIP-event kernel times, the faster of two runs of `steps`), a roofline from the NX = 6 algorithmic flops,
+    and the controls of `lanes` sampled problems against the CPU check (fp64 bar 1e-5), the lanes that are off handed to
+    the extended-precision build of the check."""
+    from oracle import oracle as orc
+    over = dict(max_iterations=args.iters, relative_exit_tol=0.0, absolute_first_derivative_tol=0.0,
+                u_guess_sinusoid_amplitude=0.0)
+    rng = np.random.default_rng(SEED + 5)
+
+    def states(spread):
+        return np.stack([rng.uniform(-0.3, 0.3, B), np.pi / 2 + rng.uniform(-spread, spread, B),
+                         np.pi / 2 + rng.uniform(-spread, spread, B), rng.uniform(-0.3, 0.3, B),
+                         rng.uniform(-0.5, 0.5, B), rng.uniform(-0.5, 0.5, B)])
+
+    res = {"note": "cart + double pendulum, B = %d, N = 40, spacing 10, %d iterations, exits disabled, cold start with a zero "
+                   "control guess; dynamics parameters %s" % (B, args.iters, DYN_DOUBLE),
+           "algorithmic_flops_per_replan": (FLOPS_NX6["linearize"] + FLOPS_NX6["qp"] + FLOPS_NX6["merit"]) * args.iters
+           + 2 * FLOPS_NX6["merit"]}
+    for start, spread in (("near_upright_0.15rad", 0.15), ("within_0.5rad", 0.5)):
+        x_np = states(spread)
+        idx = np.unique(np.linspace(0, B - 1, min(lanes, B)).astype(np.int64))
+        u_c, _, st_c, it_c, _ = orc.step_batch_cold(orc.default_opt_params(**over), DYN_DOUBLE, 0.0, x_np[:, idx], model="double")
+        rec = {}
+        for name, dt in (("f32", torch.float32), ("f64", torch.float64)):
+            x0 = torch.tensor(x_np, dtype=dt, device=dev)
+            quiesce(torch)
+            opt = pkg.BatchOptimization(pkg.default_params(**over), max_batch=B, dtype=dt, device=local_rank, model="double")
+            opt.set_pipeline(args.pipeline)
+            out = pkg.BatchOutputs()
+            for _ in range(5):
+                opt.reset()
+                opt.step(x0, DYN_DOUBLE, 0.0, out=out)
+            torch.cuda.synchronize()
+            opt.profile_enable(True)
+            el, prof = None, None
+            for _ in range(2):
+                opt.profile_reset()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    opt.reset()
+                    o = opt.step(x0, DYN_DOUBLE, 0.0, out=out)
+                torch.cuda.synchronize()
+                el_k = (time.perf_counter() - t0) / steps
+                if el is None or el_k < el:
+                    el, prof = el_k, opt.profile_read()
+            opt.profile_enable(False)
+            r = {"re-plans/s": B / el, "ms_per_step": el * 1e3, "pipeline": opt.pipeline(),
+                 "roofline": roofline_of(prof, name, B, args.iters, steps, B / el, nx=6)}
+            u_g = o.u[:, torch.as_tensor(idx, device=dev)].double().cpu().numpy()
+            st_g = o.status.cpu().numpy()[idx]
+            ps, err = parity_stats(u_g, u_c, st_g, st_c)
+            ps["bar"] = 1e-5 if name == "f64" else None
+            ps["iterations_agree"] = int((o.iterations.cpu().numpy()[idx] == it_c).sum())
+            ps["fraction_within_1e-2"] = float((err < 1e-2).mean())
+            if name == "f64" and (err > 1e-5).any():
+                off = np.where(err > 1e-5)[0][:64]
+                u_ld, _, _, _, _ = orc.step_batch_cold_ld(orc.default_opt_params(**over), DYN_DOUBLE, 0.0, x_np[:, idx[off]],
+                                                          model="double")
+                e_g = np.abs(u_g[:, off] - u_ld).max(axis=0)
+                e_c = np.abs(u_c[:, off] - u_ld).max(axis=0)
+                ps["arbiter"] = {"lanes": int(off.size), "gpu_vs_extended_max": float(e_g.max()),
+                                 "oracle_vs_extended_max": float(e_c.max()),
+                                 "lanes_gpu_at_fault": int(((e_g > 1e-5) & (e_g > 2 * e_c)).sum())}
+            r["parity_vs_cpu_check"] = ps
+            rec[name] = r
+            opt.close()
+            del opt
+        res[start] = rec
+    return res
+
+
+def plain_sqp_variant(timeout=900):
+    """What the repo's additions to the textbook SQP cost or buy: tools/plain_sqp.py in two child
+    processes -- the product with its defaults, and the -DCPMPC_SKIP_MERIT=0 build with full_step_below = 0 and
+    exit_defect_floor = 0 (the iteration of rounds 1-2) -- 262 144 controllers, 1 000-tick swing-up soak + 50 settled ticks,
+    both dtypes: ms/tick, iterations/tick, final pole error, solver failures."""
+    tool = os.path.join(ROOT, "tools", "plain_sqp.py")
+    lib = os.path.join(ROOT, "tools", "_build", "lib_noskip", "libcpmpc.so")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "CPMPC_LIB")}
+    res = {"note": "reference tolerances (optimization.hpp:30-34), 8 iterations max; `defaults` = DESIGN.md section 4 as "
+                   "shipped; `plain` = no full-step rule, no exit floor, merit evaluated on every step (-DCPMPC_SKIP_MERIT=0 "
+                   "build): what a maintainer pays for the textbook iteration"}
+    for name, e, extra in (("defaults", env, []),
+                           ("plain", dict(env, CPMPC_LIB=lib), ["--full-step-below", "0", "--exit-defect-floor", "0"])):
+        if name == "plain" and not os.path.exists(lib):
+            res[name] = {"error": "tools/_build/lib_noskip/libcpmpc.so is not built"}
+            continue
+        r = subprocess.run([sys.executable, tool] + extra, env=e, capture_output=True, text=True, timeout=timeout)
+        ln = last_json_line(r.stdout)
+        res[name] = json.loads(ln) if ln else {"error": "rc %d: %s" % (r.returncode, r.stderr[-300:])}
     return res
 
 
@@ -699,10 +873,44 @@ def arbiter(u_gpu, u_cpu, x0_np, over, worst=256):
                     "same constants)" % idx.size}
 
 
+def device_report(torch, dist, rank, world, local_rank, n_dev, backend):
+    """One line per rank, written to stderr BEFORE the timed region: which device this rank drives (ordinal, PCI bus id,
+    name), the process group's backend and size as seen from here, and which of the other visible devices this one can
+    reach peer to peer (the row of the peer-access matrix cpmpc_sharded_create would see).  Cheap insurance for the first
+    run on an 8-GPU node: a wrong device mapping or a missing xGMI link shows here, not as a hang in the gather."""
+    try:
+        bus = torch.cuda.get_device_properties(local_rank)
+        pci = "%04x:%02x:%02x" % (getattr(bus, "pci_domain_id", 0), getattr(bus, "pci_bus_id", -1) & 0xff, getattr(bus, "pci_device_id", 0))
+        name = bus.name
+    except Exception as exc:  # noqa: BLE001
+        pci, name = "?", "? (%s)" % exc
+    peers = []
+    for j in range(n_dev):
+        if j == local_rank:
+            peers.append("-")
+            continue
+        try:
+            peers.append("1" if torch.cuda.can_device_access_peer(local_rank, j) else "0")
+        except Exception:  # noqa: BLE001
+            peers.append("?")
+    pg = "none"
+    if backend is not None and dist.is_initialized():
+        pg = "%s world %d" % (dist.get_backend(), dist.get_world_size())
+    vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or "all"
+    return ("bench.py rank %d/%d: device %d of %d visible (%s) pci %s '%s'; process group %s; peer access to devices [%s]; "
+            "HSA_ENABLE_IPC_MODE_LEGACY=%s" % (rank, world, local_rank, n_dev, vis, pci, name, pg, " ".join(peers),
+                                                os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "unset")))
+
+
 def run_rank(args):
     import torch
     import torch.distributed as dist
 
+    # Python's cyclic collector is off for the whole run: a generation-2 pass of a process that has torch loaded takes
+    # ~40 ms, and when it lands in a timed loop that synchronises per tick the device idles for all of it (seen: one block of
+    # 50 settled ticks at 1.56 ms per tick between blocks at 0.77).  quiesce() and timed_region() collect explicitly, outside
+    # the timed steps.
+    gc.disable()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -743,6 +951,9 @@ def run_rank(args):
 
     pkg = importlib.import_module("cart-pole-mpc_amd")
     sharding = importlib.import_module("cart-pole-mpc_amd.sharding")
+    if distributed or world > 1:
+        sys.stderr.write(device_report(torch, dist, rank, world, local_rank, n_dev, backend if distributed else None) + "\n")
+        sys.stderr.flush()
     tdt = torch.float32 if args.dtype == "f32" else torch.float64
     B = args.batch
     over = dict(max_iterations=args.iters, relative_exit_tol=0.0, absolute_first_derivative_tol=0.0)
@@ -763,8 +974,8 @@ def run_rank(args):
         gather = sharding.ResultGather(N, B, tdt, dev, dst=0, depth=2, force=force_dist,
                                        via_host=(backend == "gloo"))
 
-    elapsed, own_s, prof, out, slot = timed_region(torch, dist, sharding, opt, x0, outs, gather, args.steps, args.warmup,
-                                                   dev, local_rank, distributed)
+    elapsed, own_s, prof, out, slot, n_pre = timed_region(torch, dist, sharding, opt, x0, outs, gather, args.steps, args.warmup,
+                                                          dev, local_rank, distributed, preheat_s=args.preheat_seconds)
 
     # the gather on its own: the same [N, B] block from every rank to rank 0, nothing else in flight
     gather_ms = None
@@ -801,6 +1012,7 @@ def run_rank(args):
         "value": value, "unit": "re-plans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "preheated": args.preheat_seconds > 0.0, "preheat_s": args.preheat_seconds, "preheat_steps": n_pre,
         "config": {"workload": "BASELINE configs[%d]%s: batch=%d per GPU (%d in total), N=40, state_spacing=10, %s, cold start, "
                                "%d SQP iterations (exits disabled), u+predicted+status written%s"
                                % (2 if shard_world == 1 else 3,
@@ -870,11 +1082,13 @@ def run_rank(args):
             opt64.set_pipeline(args.pipeline)
             x64 = torch.tensor(x0_np, dtype=torch.float64, device=dev)
             outs64 = [pkg.BatchOutputs(), pkg.BatchOutputs()]
-            el64, _, prof64, o64, _ = timed_region(torch, dist, sharding, opt64, x64, outs64, None, args.steps, args.warmup,
-                                                dev, local_rank, False)
+            el64, _, prof64, o64, _, n_pre64 = timed_region(torch, dist, sharding, opt64, x64, outs64, None, args.steps,
+                                                            args.warmup, dev, local_rank, False,
+                                                            preheat_s=min(args.preheat_seconds, 1.0))
             v64 = B * args.steps / el64
             line["fp64"] = {"value": v64, "unit": "re-plans/s", "dtype": "f64", "steps": args.steps, "warmup": args.warmup,
                             "ms_per_step": el64 / args.steps * 1e3, "batch": B, "pipeline": opt64.pipeline(),
+                            "preheat_steps": n_pre64,
                             "roofline": roofline_of(prof64, "f64", B, args.iters, args.steps, v64),
                             "note": "the parity dtype (the reference computes in double only): the workload of the "
                                     "timed region in fp64 at the same batch, timed the same way"}
@@ -926,6 +1140,30 @@ def run_rank(args):
                 line["parity_sample"] = ps
             except Exception as exc:  # noqa: BLE001
                 line["parity_sample"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            if args.dtype == "f32":
+                # the same lanes against the SINGLE-PRECISION build of the CPU check (oracle/cpmpc_oracle_f32.c): how far
+                # the float kernels are from a same-precision answer, next to how far that answer is from the double one
+                try:
+                    from oracle import oracle as orc
+                    m = min(n, 8192)
+                    u_f, st_f, _, _, _ = orc.step_batch_cold_f32(orc.default_opt_params(**over), DYN_UI, 0.0, x0_np[:, :m],
+                                                                 num_threads=base["cores"])
+                    u_g = u_primary[:, :m].double().cpu().numpy()
+                    e_gf = np.abs(u_g - u_f).max(axis=0)
+                    e_fd = np.abs(u_f - u_cpu[:, :m]).max(axis=0)
+                    e_gd = np.abs(u_g - u_cpu[:, :m]).max(axis=0)
+                    q = lambda e: {"median": float(np.median(e)), "p90": float(np.quantile(e, 0.9)), "p99": float(np.quantile(e, 0.99)),  # noqa: E731
+                                   "within_1e-2": float((e < 1e-2).mean())}
+                    line["parity_vs_f32_check"] = {
+                        "lanes": int(m), "gpu_f32_vs_cpu_f32": q(e_gf), "cpu_f32_vs_cpu_f64": q(e_fd), "gpu_f32_vs_cpu_f64": q(e_gd),
+                        "status_agree_gpu_f32_vs_cpu_f32": int((st[:m] == st_f).sum()),
+                        "note": "max |du| per lane, three pairings of the same lanes.  The single-precision CPU check is the same "
+                                "restatement compiled in float with its dense KKT solve in double (the kernels keep only "
+                                "their terminal system in double and take sin / cos / exp from the hardware's approximations): "
+                                "read cpu_f32_vs_cpu_f64 as what single precision costs this algorithm at best, and "
+                                "gpu_f32_vs_cpu_f32 as what the float kernels add to it"}
+                except Exception as exc:  # noqa: BLE001
+                    line["parity_vs_f32_check"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
             if u64 is not None:
                 try:
                     ps64, _ = parity_stats(u64[:, :n], u_cpu, st64[:n], st_cpu)
@@ -952,6 +1190,8 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=262144, help="problems per GPU")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--preheat-seconds", type=float, default=2.0, help="untimed pre-heat of the same steps before the "
+                    "warm-up (0 disables); the timed region stays exactly --steps after --warmup")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-fp64", action="store_true", help="skip the fp64 record")

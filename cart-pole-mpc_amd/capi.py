@@ -38,7 +38,7 @@ SYMBOLS = [
     "cpmpc_model", "cpmpc_dynamics_batch_model", "cpmpc_rk4_batch_model", "cpmpc_sim_step_batch_model",
     "cpmpc_set_pipeline", "cpmpc_get_pipeline", "cpmpc_set_compaction", "cpmpc_get_stage_plan", "cpmpc_plan_stages_from_histogram",
     "cpmpc_profile_enable", "cpmpc_profile_reset", "cpmpc_profile_read", "cpmpc_kernel_name",
-    "cpmpc_sharded_create", "cpmpc_sharded_destroy", "cpmpc_sharded_num_shards", "cpmpc_sharded_device",
+    "cpmpc_sharded_create", "cpmpc_sharded_destroy", "cpmpc_sharded_num_shards", "cpmpc_sharded_device", "cpmpc_sharded_peer_access",
     "cpmpc_sharded_handle", "cpmpc_sharded_range", "cpmpc_sharded_reset", "cpmpc_sharded_step_batch_host",
     "cpmpc_sharded_step_batch", "cpmpc_sharded_create_ex", "cpmpc_sharded_previous_solution_batch",
     "cpmpc_sharded_set_previous_solution", "cpmpc_sharded_set_previous_solution_host", "cpmpc_sharded_get_solution",
@@ -247,6 +247,8 @@ def load():
     L.cpmpc_sharded_destroy.argtypes = [vp]
     L.cpmpc_sharded_destroy.restype = None
     L.cpmpc_sharded_num_shards.argtypes = [vp]
+    L.cpmpc_sharded_peer_access.argtypes = [vp, i32]
+    L.cpmpc_sharded_peer_access.restype = i32
     L.cpmpc_sharded_device.argtypes = [vp, i32]
     L.cpmpc_sharded_handle.argtypes = [vp, i32]
     L.cpmpc_sharded_handle.restype = vp

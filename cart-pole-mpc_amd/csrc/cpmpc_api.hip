@@ -1033,6 +1033,7 @@ struct Shard {
   hipEvent_t done = nullptr;      // shard stream -> root stream (results have landed on the root device)
   void* buf = nullptr;            // per-shard device staging of the device-pointer step and of the warm-start hand-over
   size_t buf_bytes = 0;
+  int peer = 1;                   // what cpmpc_sharded_create saw: 1 root <-> this device mapped both ways (or the same device), 0 not
 };
 
 struct cpmpc_sharded {
@@ -1136,15 +1137,18 @@ extern "C" int cpmpc_sharded_create_ex(const cpmpc_create_info* info, const int*
   for (int i = 1; i < n; ++i) {
     const int d = s->shards[i].device;
     if (d == root) continue;
-    int can = 0;
+    int can = 0, both = 0;
     if (hipDeviceCanAccessPeer(&can, root, d) == hipSuccess && can) {
       DeviceGuard guard(root);
-      (void)hipDeviceEnablePeerAccess(d, 0);
+      const hipError_t pe = hipDeviceEnablePeerAccess(d, 0);
+      both += (pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled);
     }
     if (hipDeviceCanAccessPeer(&can, d, root) == hipSuccess && can) {
       DeviceGuard guard(d);
-      (void)hipDeviceEnablePeerAccess(root, 0);
+      const hipError_t pe = hipDeviceEnablePeerAccess(root, 0);
+      both += (pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled);
     }
+    s->shards[i].peer = both == 2;
     (void)hipGetLastError();  // "already enabled" is fine
   }
   *out = s;
@@ -1167,6 +1171,9 @@ extern "C" int cpmpc_sharded_create(const cpmpc_params* params, const cpmpc_solv
 }
 
 extern "C" int cpmpc_sharded_num_shards(const cpmpc_sharded* s) { return s ? (int)s->shards.size() : -1; }
+extern "C" int cpmpc_sharded_peer_access(const cpmpc_sharded* s, int shard) {
+  return (s && shard >= 0 && shard < (int)s->shards.size()) ? s->shards[shard].peer : -1;
+}
 extern "C" int cpmpc_sharded_device(const cpmpc_sharded* s, int shard) {
   return (s && shard >= 0 && shard < (int)s->shards.size()) ? s->shards[shard].device : -1;
 }

@@ -130,8 +130,8 @@ static inline bool fused_static(int L, int SP) {  // the default horizon's spaci
 // ... and a run-time-spacing variant (dynamic LDS) for any other spacing with one of these interval counts whose
 // per-wave LDS (80 scalars per lane and control for NX = 4) fits the 64 KB a dynamic allocation may take
 static inline size_t fused_dyn_bytes(const cpmpc_solver* s) {
-  const size_t xw = s->NX > 4 ? 8 : 4;
-  return (size_t)s->SP * 64 * (4 + xw) * s->esize;
+  const size_t g_bytes = ((size_t)s->NX * s->esize + 15) / 16 * 16;  // a column of Gamma in 16-byte pieces (mpc_fused.hpp)
+  return (size_t)s->SP * 64 * (4 * (size_t)s->esize + g_bytes);
 }
 static inline bool fused_dynamic(const cpmpc_solver* s) {
   const int L = s->S - 1;
@@ -140,12 +140,26 @@ static inline bool fused_dynamic(const cpmpc_solver* s) {
 }
 static inline bool fused_built(const cpmpc_solver* s) { return fused_static(s->S - 1, s->SP) || fused_dynamic(s); }
 
+// LDS a wave of the fused kernel takes for this handle (mpc_fused.hpp: u, du, (U^-1 g), 1/d per control and lane plus a
+// column of Gamma in 16-byte pieces; the slim layout of the double 6-state kernel keeps u, du and Gamma only)
+static inline size_t fused_wave_lds_bytes(const cpmpc_solver* s) {
+  const size_t g_bytes = ((size_t)s->NX * s->esize + 15) / 16 * 16;
+  const bool slim = s->esize == 8 && s->NX > 4 && !s->refine_qp && s->SP <= 10 && fused_static(s->S - 1, s->SP);
+  return (size_t)s->SP * 64 * ((slim ? 2 : 4) * (size_t)s->esize + g_bytes);
+}
+
 static inline bool use_fused(const cpmpc_solver* s) {
   if (s->pipeline == CPMPC_PIPELINE_SPLIT) return false;
   if (!fused_built(s)) return false;
-  // AUTO: the 6-state model in fp64 needs 61 KB of LDS per wave in the fused kernel (2 waves per CU); the split
-  // pipeline is as fast there (measured 10.1 vs 9.7 M re-plans/s), so it stays the default for that case
-  if (s->pipeline == CPMPC_PIPELINE_AUTO && s->model == CPMPC_MODEL_DOUBLE && s->dtype == CPMPC_F64) return false;
+  // AUTO: the double kernel of the 6-state model, which holds all 512 registers (one wave per SIMD at best), runs fused
+  // where at least three of its waves fit a CU's 160 KB of LDS: 40 KB per wave at
+  // state_spacing 10 since round 5 (four per CU: 23.4 M re-plans/s at B = 65 536 against 13.7 M split; with the padded
+  // 60 KB layout of rounds 1-4, two per CU, it was 14.4 M and AUTO kept the split pipeline), 100 KB at spacing 20 (one per
+  // CU: split).
+  // (the other kernels keep what rounds 1-4 measured for them: fused wherever built)
+  if (s->pipeline == CPMPC_PIPELINE_AUTO && s->model == CPMPC_MODEL_DOUBLE && s->dtype == CPMPC_F64 &&
+      3 * fused_wave_lds_bytes(s) > 160u * 1024u)
+    return false;
   return true;
 }
 

@@ -271,6 +271,17 @@ template <typename R, typename M, int SP>
 __host__ __device__ constexpr bool fused_lean() {
   return CPMPC_FUSED_LEAN_LDS && sizeof(R) == 4 && M::NX <= 4 && SP <= 10;
 }
+// Slim layout for the double kernel of the 6-state model (round 5): with (U^-1 g)_k in the slot of du_k (as in the lean
+// layout above) and the 1/d_k of a lane's controls in registers, a wave needs u + du + Gamma = (8 + 8 + 48) x SP x 64 bytes
+// = 40 KB at SP = 10 instead of 60 KB: four waves per CU -- one per SIMD, all the 512-register kernel can use -- instead of
+// two.  Not for the REFINE instantiation (its second solve needs gw and du side by side).
+#ifndef CPMPC_FUSED_SLIM_F64_NX6
+#define CPMPC_FUSED_SLIM_F64_NX6 1
+#endif
+template <typename R, typename M, int SP, bool REFINE>
+__host__ __device__ constexpr bool fused_slim() {
+  return CPMPC_FUSED_SLIM_F64_NX6 && sizeof(R) == 8 && M::NX > 4 && !REFINE && SP <= 10;
+}
 #undef CPMPC_FUSED_BOUNDS
 #define CPMPC_FUSED_BOUNDS_S __launch_bounds__(64, (fused_lean<R, M, SP>() ? 3 : ((sizeof(R) == 4 && M::NX <= 4) ? CPMPC_FUSED_WAVES_F32 : 1)))
 #define CPMPC_FUSED_BOUNDS __launch_bounds__(64, ((sizeof(R) == 4 && M::NX <= 4) ? CPMPC_FUSED_WAVES_F32 : 1))
@@ -293,9 +304,15 @@ __host__ __device__ constexpr bool fused_lean() {
 struct alignas(16) GPiece {
   unsigned w[4];
 };
+// Round 5: a column occupies only the 16-byte pieces it fills -- 48 bytes instead of the padded 64 for double / NX = 6
+// (CPMPC_FUSED_G_UNPADDED = 0 restores the padded element): Gamma is 30 KB instead of 40 KB per wave there, the kernel's
+// LDS 50 KB instead of 60 KB, three waves per CU instead of two.  Float / NX = 6 (24 bytes) still takes two pieces.
+#ifndef CPMPC_FUSED_G_UNPADDED
+#define CPMPC_FUSED_G_UNPADDED 1
+#endif
 template <typename R, int NX>
 __host__ __device__ constexpr int fused_g_pieces() {
-  return (int)(sizeof(XV<R, NX>) / 16);
+  return CPMPC_FUSED_G_UNPADDED ? (int)((NX * sizeof(R) + 15) / 16) : (int)(sizeof(XV<R, NX>) / 16);
 }
 template <typename R, int NX>
 __device__ __forceinline__ XV<R, NX> fused_g_ld(const GPiece* g, int i, int lane) {
@@ -304,14 +321,14 @@ __device__ __forceinline__ XV<R, NX> fused_g_ld(const GPiece* g, int i, int lane
   GPiece pc[K];
 #pragma unroll
   for (int p = 0; p < K; ++p) pc[p] = CPMPC_FUSED_G_PLANES ? g[(i * K + p) * 64 + lane] : g[(i * 64 + lane) * K + p];
-  __builtin_memcpy(&v, pc, sizeof v);
+  __builtin_memcpy(&v, pc, sizeof pc <= sizeof v ? sizeof pc : sizeof v);  // (the padding of v, if any, is never read)
   return v;
 }
 template <typename R, int NX>
 __device__ __forceinline__ void fused_g_st(GPiece* g, int i, int lane, const XV<R, NX> v) {
   constexpr int K = fused_g_pieces<R, NX>();
   GPiece pc[K];
-  __builtin_memcpy(pc, &v, sizeof v);
+  __builtin_memcpy(pc, &v, sizeof pc <= sizeof v ? sizeof pc : sizeof v);
 #pragma unroll
   for (int p = 0; p < K; ++p) {
     if (CPMPC_FUSED_G_PLANES) g[(i * K + p) * 64 + lane] = pc[p];
@@ -326,7 +343,8 @@ template <typename R, typename M, int SP, int L, bool SHARED, bool REFINE>
 __global__ CPMPC_FUSED_BOUNDS_S CPMPC_FUSED_EXTRA_ATTR void fused_sqp_kernel(const SolverArgs<R, M> a, const int max_iters) {
   constexpr int NX = M::NX;
   constexpr int PPW = 64 / L;  // problems per wave
-  constexpr bool kLean = fused_lean<R, M, SP>();
+  constexpr bool kSlim = fused_slim<R, M, SP, REFINE>();
+  constexpr bool kLean = fused_lean<R, M, SP>() || kSlim;
   __shared__ R lds_u[SP * 64];
   __shared__ R lds_du[SP * 64];
   __shared__ GPiece lds_G[SP * 64 * fused_g_pieces<R, NX>()];  // column i of my Gamma_s (fused_g_ld / fused_g_st)
@@ -334,7 +352,7 @@ __global__ CPMPC_FUSED_BOUNDS_S CPMPC_FUSED_EXTRA_ATTR void fused_sqp_kernel(con
 #ifndef CPMPC_FUSED_ID_REGS
 #define CPMPC_FUSED_ID_REGS 0  // 1: 1/d_k in registers (15 KB of LDS, but the full unroll it needs spills 151 values: slower)
 #endif
-  constexpr bool kIdRegs = kLean && CPMPC_FUSED_ID_REGS;
+  constexpr bool kIdRegs = (fused_lean<R, M, SP>() && CPMPC_FUSED_ID_REGS) || kSlim;
   __shared__ R lds_id[kIdRegs ? 1 : SP * 64];      // 1/d_k of my controls
   R* const lds_gw = kLean ? lds_du : lds_gw_own;
   R id_reg[kIdRegs ? SP : 1];
@@ -365,7 +383,7 @@ __global__ CPMPC_FUSED_BOUNDS_S CPMPC_FUSED_EXTRA_ATTR void fused_sqp_kernel(con
 // carved from dynamic shared memory (fused_dyn_lds_bytes), the matrix powers use a run-time exponent.
 template <typename R, typename M>
 __host__ __device__ constexpr size_t fused_dyn_lds_bytes(int sp) {
-  return (size_t)sp * 64 * (4 * sizeof(R) + sizeof(XV<R, M::NX>));
+  return (size_t)sp * 64 * (4 * sizeof(R) + 16 * (size_t)fused_g_pieces<R, M::NX>());
 }
 template <typename R, typename M, int L, bool SHARED, bool REFINE>
 __global__ CPMPC_FUSED_BOUNDS void fused_sqp_dyn_kernel(const SolverArgs<R, M> a, const int max_iters) {

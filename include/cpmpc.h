@@ -378,6 +378,10 @@ int cpmpc_sharded_create_ex(const cpmpc_create_info* info, const int* devices, i
 void cpmpc_sharded_destroy(cpmpc_sharded* s);
 int cpmpc_sharded_num_shards(const cpmpc_sharded* s);
 int cpmpc_sharded_device(const cpmpc_sharded* s, int shard);          /* HIP device of a shard; -1 if out of range */
+/* What cpmpc_sharded_create saw for this shard's device: 1 peer access between it and the root device (shard 0's) is
+ * mapped in both directions (or it IS the root device) -- its slices travel device to device over xGMI; 0 not -- the
+ * runtime stages those copies through host memory (slower, still correct); -1 out of range. */
+int cpmpc_sharded_peer_access(const cpmpc_sharded* s, int shard);
 cpmpc_solver* cpmpc_sharded_handle(cpmpc_sharded* s, int shard);      /* the shard's own solver (options, profiling) */
 /* columns [*lo, *hi) of a B-problem batch that shard `shard` solves */
 int cpmpc_sharded_range(const cpmpc_sharded* s, int shard, int64_t B, int64_t* lo, int64_t* hi);

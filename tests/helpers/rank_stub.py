@@ -19,6 +19,9 @@ args = bench.parse_args(sys.argv[1:])
 world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
 if os.environ.get("CPMPC_STUB_FAIL_RANK") is not None:   # a rank that dies early while the others would wait for it
     if rank == int(os.environ["CPMPC_STUB_FAIL_RANK"]):
+        for i in range(60):   # more than the launcher relays: the LAST 40 must be the ones it prints
+            sys.stderr.write("stub rank %d diagnostic line %d\n" % (rank, i))
+        sys.stderr.write("stub rank %d: ncclCommInitRank failed (pretend)\n" % rank)
         sys.exit(3)
     import time
     time.sleep(120)

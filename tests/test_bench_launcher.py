@@ -75,6 +75,59 @@ def test_a_rank_that_dies_ends_the_run_at_once(monkeypatch):
         assert rc == 3 and time.monotonic() - t0 < 60
 
 
+def test_a_failing_rank_leaves_its_last_stderr_lines(monkeypatch, capfd):
+    """when a rank exits non-zero the launcher prints that rank's last 40 stderr lines under its verdict
+    (the stub's failing rank writes 61 lines; the first 21 must not be in the excerpt, the last one must)."""
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setenv("CPMPC_STUB_FAIL_RANK", "1")
+    rc, _ = bench.launch_ranks(2, ["--gpus", "2"], n_devices=2, script=STUB, timeout=300)
+    assert rc == 3
+    err = capfd.readouterr().err
+    assert "rank 1 exited with code 3" in err
+    head, _, excerpt = err.partition("last 40 stderr line(s) of rank 1:")
+    assert excerpt, err[-2000:]
+    lines = [ln for ln in excerpt.splitlines() if ln.startswith("    | ")]
+    assert len(lines) == 40
+    assert lines[-1].endswith("stub rank 1: ncclCommInitRank failed (pretend)")
+    assert "diagnostic line 20" not in excerpt and "diagnostic line 21" in excerpt
+    assert "[rank 1] stub rank 1 diagnostic line 0" in head      # the full stderr of every rank is relayed as well
+
+
+def test_device_report_names_device_backend_and_peers():
+    """The line every rank writes before the timed region (no GPU needed: a stand-in for torch.cuda)."""
+    class Props:
+        name, pci_domain_id, pci_bus_id, pci_device_id = "AMD Instinct MI355X", 0, 0x85, 0
+
+    class Cuda:
+        @staticmethod
+        def get_device_properties(i):
+            return Props
+
+        @staticmethod
+        def can_device_access_peer(a, b):
+            return b != 3
+
+    class Torch:
+        cuda = Cuda
+
+    class Dist:
+        @staticmethod
+        def is_initialized():
+            return True
+
+        @staticmethod
+        def get_backend():
+            return "nccl"
+
+        @staticmethod
+        def get_world_size():
+            return 8
+
+    ln = bench.device_report(Torch, Dist, 2, 8, 2, 4, "nccl")
+    assert "rank 2/8" in ln and "device 2 of 4" in ln and "0000:85:00" in ln and "MI355X" in ln
+    assert "process group nccl world 8" in ln and "peer access to devices [1 1 - 0]" in ln
+
+
 def test_launcher_overall_timeout(monkeypatch):
     import time
     monkeypatch.delenv("WORLD_SIZE", raising=False)

@@ -173,13 +173,20 @@ def test_double_closed_loop_and_warm_start(pkg, orc):
 
 
 def test_config5_full_size(pkg, orc):
-    """BASELINE configs[4]: double pendulum, batch = 65536, N = 40, one GPU.  fp32 run: finite, clamped,
-    deterministic; fp64 run: sampled lanes within 1e-5 of the oracle."""
+    """BASELINE configs[4]: double pendulum, batch = 65536, N = 40, one GPU, the default pipeline (fused in both dtypes
+    since round 5).  Half of the batch starts near upright (both poles within 0.15 rad), the other half anywhere within
+    0.5 rad of upright with larger velocities (the round-4 form of this test sampled 256 near-upright lanes).
+    fp32 run: finite, clamped, deterministic; fp64 run: 4 096 sampled lanes -- the first and last waves of each half and an
+    even spread -- within 1e-5 of the oracle on u, same termination state and iteration count."""
     rng = np.random.default_rng(50)
     B = 65536
     x0 = near_upright(rng, B)
+    h = B // 2
+    x0[1:3, h:] = np.pi / 2 + rng.uniform(-0.5, 0.5, (2, B - h))
+    x0[3:, h:] = rng.uniform(-1.0, 1.0, (3, B - h))
     over = dict(OVER, max_iterations=5, relative_exit_tol=0.0, absolute_first_derivative_tol=0.0)
     opt32 = pkg.BatchOptimization(pkg.default_params(**over), max_batch=B, dtype=torch.float32, device=0, model="double")
+    assert opt32.pipeline() == "fused"
     o1 = opt32.step(T(x0, torch.float32), DYN, 0.0)
     u1, st1 = o1.u.clone(), o1.status.clone()
     assert torch.isfinite(u1).all() and u1.abs().max().item() <= 300.0
@@ -189,11 +196,21 @@ def test_config5_full_size(pkg, orc):
     assert torch.equal(o2.u, u1) and torch.equal(o2.status, st1)
     del opt32
     opt64 = pkg.BatchOptimization(pkg.default_params(**over), max_batch=B, dtype=torch.float64, device=0, model="double")
+    assert opt64.pipeline() == "fused"
     out = opt64.step(T(x0), DYN, 0.0)
-    samp = np.concatenate([np.arange(64), np.arange(B - 64, B), rng.integers(0, B, 128)])
-    u_cpu, _, st_cpu, _, _ = orc.step_batch_cold(orc.default_opt_params(**over), DYN, 0.0, x0[:, samp], model="double")
+    samp = np.unique(np.concatenate([np.arange(64), np.arange(h - 64, h + 64), np.arange(B - 64, B),
+                                     np.linspace(0, B - 1, 3900).astype(np.int64)]))
+    assert samp.size >= 4096 and (samp >= h).sum() > 1900
+    u_cpu, _, st_cpu, it_cpu, _ = orc.step_batch_cold(orc.default_opt_params(**over), DYN, 0.0, x0[:, samp], model="double")
     err = np.abs(N_(out.u)[:, samp] - u_cpu).max(axis=0)
-    assert (N_(out.status)[samp] == st_cpu).all()
-    assert err.max() < 1e-5, np.sort(err)[-5:]
+    assert (N_(out.status)[samp] == st_cpu).all() and (N_(out.iterations)[samp] == it_cpu).all()
+    if not (err < 1e-5).all():   # who moved?  (oracle/cpmpc_oracle_ld.c)
+        off = np.where(err >= 1e-5)[0]
+        u_ld, _, _, _, _ = orc.step_batch_cold_ld(orc.default_opt_params(**over), DYN, 0.0, x0[:, samp[off]], model="double")
+        e_g = np.abs(N_(out.u)[:, samp[off]] - u_ld).max(axis=0)
+        e_c = np.abs(u_cpu[:, off] - u_ld).max(axis=0)
+        raise AssertionError("lanes beyond 1e-5: %s; GPU vs extended %s, oracle vs extended %s" % (samp[off], e_g, e_c))
     e32 = np.abs(N_(u1.double())[:, samp] - u_cpu).max(axis=0)
-    print("config 5: fp64 |du| max %.2e median %.2e;  fp32 median %.2e" % (err.max(), np.median(err), np.median(e32)))
+    far = samp >= h
+    print("config 5: fp64 |du| max %.2e median %.2e (near upright max %.2e, within 0.5 rad max %.2e);  fp32 median %.2e"
+          % (err.max(), np.median(err), err[~far].max(), err[far].max(), np.median(e32)))

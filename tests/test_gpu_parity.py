@@ -869,8 +869,16 @@ def test_pipeline_selection(pkg):
                                   dtype=torch.float32, device=0, allow_long_horizon=N > 80)
         assert o.pipeline() == want, (N, sp)
     opt3 = pkg.BatchOptimization(pkg.default_params(), max_batch=64, dtype=torch.float32, device=0, model="double")
-    assert opt3.pipeline() == "fused"                  # both models are built; fp64 double defaults to split (LDS)
+    assert opt3.pipeline() == "fused"                  # both models are built
+    # fp64 double: fused where three waves of it fit a CU's LDS (round 5: 40 KB per wave at spacing 10, 50 KB with the QP
+    # refinement; rounds 1-4 needed 60 KB and defaulted to split), split where they do not (100 KB at spacing 20)
     opt4 = pkg.BatchOptimization(pkg.default_params(), max_batch=64, dtype=torch.float64, device=0, model="double")
-    assert opt4.pipeline() == "split"
-    opt4.set_pipeline("fused")
     assert opt4.pipeline() == "fused"
+    opt4.set_pipeline("split")
+    assert opt4.pipeline() == "split"
+    opt5 = pkg.BatchOptimization(pkg.default_params(), max_batch=64, dtype=torch.float64, device=0, model="double", refine_qp=True)
+    assert opt5.pipeline() == "fused"
+    opt6 = pkg.BatchOptimization(pkg.default_params(state_spacing=20), max_batch=64, dtype=torch.float64, device=0, model="double")
+    assert opt6.pipeline() == "split"
+    opt6.set_pipeline("fused")
+    assert opt6.pipeline() == "fused"

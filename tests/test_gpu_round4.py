@@ -420,9 +420,17 @@ def test_sharded_device_step_takes_per_problem_inputs_and_returns_the_solution(p
     params = pkg.default_params(**NO_TOL)
     stream = torch.cuda.current_stream().cuda_stream
     if layout == "one_shard_per_gpu":
+        # A skip must mean "one GPU", never "the library miscounted": the library's count, torch's and the KFD topology in
+        # sysfs (narrowed by a *_VISIBLE_DEVICES list) have to agree before the test may skip (in
+        # GPUTEST a silent skip on an 8-GPU node would read like a pass)
+        import bench
         n_gpus = lib.cpmpc_device_count()
+        n_torch = torch.cuda.device_count()
+        n_sysfs = bench.visible_gpus()
+        assert n_gpus == n_torch, "cpmpc_device_count() = %d but torch sees %d devices" % (n_gpus, n_torch)
+        assert n_sysfs in (0, n_gpus), "the KFD topology shows %d GPUs, the library %d" % (n_sysfs, n_gpus)
         if n_gpus < 2:
-            pytest.skip("needs at least two GPUs (this box has %d)" % n_gpus)
+            pytest.skip("one GPU on this box (library, torch and sysfs agree: %d / %d / %d)" % (n_gpus, n_torch, n_sysfs))
         shard_devices = list(range(min(n_gpus, 8)))
     else:
         shard_devices = [0, 0, 0]
@@ -459,6 +467,13 @@ def test_sharded_device_step_takes_per_problem_inputs_and_returns_the_solution(p
     devs = (C.c_int * len(shard_devices))(*shard_devices)
     pkg.capi.check(lib.cpmpc_sharded_create(C.byref(params), None, cdt, B, devs, len(shard_devices), C.byref(sharded)))
     dim = lib.cpmpc_dim(single)
+    for i in range(len(shard_devices)):   # what the library saw when it mapped the devices onto each other
+        assert lib.cpmpc_sharded_device(sharded, i) == shard_devices[i]
+        assert lib.cpmpc_sharded_peer_access(sharded, i) in (0, 1)
+    if layout != "one_shard_per_gpu":
+        assert all(lib.cpmpc_sharded_peer_access(sharded, i) == 1 for i in range(3))   # the root device itself
+    else:
+        print("peer access root <-> shard devices:", [lib.cpmpc_sharded_peer_access(sharded, i) for i in range(len(shard_devices))])
     try:
         # per-problem inputs, then shared ones warm-started from them; then other batch sizes (growing, shrinking)
         for nb, per_problem in ((B, True), (B, False), (2000, True), (B, False), (1234, False)):

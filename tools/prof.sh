@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 cd /tmp
 O="$R/gpurun_out/prof_$TAG"
 mkdir -p "$O"
-COMMON=(--no-cpu-baseline --no-variants --no-fp64 --no-clock "${EXTRA[@]}")
+COMMON=(--no-cpu-baseline --no-variants --no-fp64 --no-clock --preheat-seconds 0 "${EXTRA[@]}")
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -- python3 "$R/bench.py" --steps 10 --warmup 2 "${COMMON[@]}" > "$O/kt.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/fetch" -- python3 "$R/bench.py" --steps 3 --warmup 1 "${COMMON[@]}" > "$O/fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/write" -- python3 "$R/bench.py" --steps 3 --warmup 1 "${COMMON[@]}" > "$O/write.log" 2>&1
