@@ -579,6 +579,7 @@ def variants(torch, pkg, args, tdt, dev, local_rank, x0, B):
         if tdt == torch.float32:
             res["closed_loop_settled"]["f32_fo_tol_1e-4"] = closed_loop(tdt, settle=300, absolute_first_derivative_tol=1e-4)
             res["closed_loop_settled"]["f64"] = closed_loop(torch.float64, settle=300)
+        res["closed_loop_settled"]["column_ranges"] = closed_loop_ranges(torch, pkg, args, dev, local_rank, B, xs)
     except Exception as exc:  # noqa: BLE001
         res["closed_loop_settled"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     try:
@@ -670,6 +671,44 @@ def per_problem_variant(torch, pkg, args, dev, local_rank, B, lanes=4096, steps=
         rec["parity_vs_cpu_check"] = ps
         res[name] = rec
         del opt
+    return res
+
+
+def closed_loop_ranges(torch, pkg, args, dev, local_rank, B, xs, settle=300, ticks=100):
+    """The settled closed loop held as 1, 2 and 3 independent column ranges (pkg.ClosedLoop: own handle, plant and stream
+    each, no synchronisation between them): ms per tick (the best of three runs of `ticks`) and that controls and plant
+    states are bitwise those of the single range.  Ranges drift out of phase, so one range's prepare / plant / finalize
+    runs beside another's fused SQP kernel (which leaves issue slots idle at one wave per SIMD)."""
+    res = {"note": "300 untimed ticks, then the best of 3 x %d timed; reference defaults; 262 144 controllers from within 0.4 rad of "
+                   "upright" % ticks}
+    for name, dt, parts in (("f64", torch.float64, (1, 2)), ("f32", torch.float32, (1, 3))):
+        rec, ref = {}, None
+        for n in parts:
+            quiesce(torch)
+            loop = pkg.ClosedLoop(pkg.default_params(), B, dtype=dt, device=local_rank, ranges=n, pipeline=args.pipeline)
+            loop.set_state(torch.tensor(xs, dtype=dt, device=dev))
+            for _ in range(settle):
+                loop.tick(DYN_UI, 0.0)
+            quiesce(torch)
+            best = None
+            for _ in range(3):
+                t0 = time.perf_counter()
+                for _ in range(ticks):
+                    loop.tick(DYN_UI, 0.0)
+                torch.cuda.synchronize()
+                el = (time.perf_counter() - t0) / ticks
+                best = el if best is None or el < best else best
+            u, x = loop.controls(), loop.state()
+            r = {"ms_per_tick": best * 1e3, "mean_iterations": float(loop.iterations().float().mean().item())}
+            if ref is None:
+                ref = (u.clone(), x.clone())
+            else:
+                r["bitwise_equal_to_one_range"] = bool(torch.equal(u, ref[0]) and torch.equal(x, ref[1]))
+                r["speedup"] = rec["ranges_1"]["ms_per_tick"] / r["ms_per_tick"]
+            rec["ranges_%d" % n] = r
+            loop.close()
+            del loop
+        res[name] = rec
     return res
 
 

@@ -8,7 +8,7 @@ Contents:
     csrc/      HIP kernels (gfx950) + the C-ABI implementation (include/cpmpc.h)
     lib/       libcpmpc.so (built by build.py / __graft_entry__.build(); git-ignored)
     capi.py    ctypes binding of the C-ABI
-    batch.py   batched host API on torch tensors (BatchOptimization, BatchSimulator)
+    batch.py   batched host API on torch tensors (BatchOptimization, BatchSimulator, ClosedLoop)
     host/      C++ facade with the reference's class API + the pypendulum binding
 """
 from . import capi  # noqa: F401
@@ -17,7 +17,7 @@ from .capi import CpmpcError, Params, SolverOpts, default_params, default_solver
 
 def __getattr__(name):
     # torch-dependent pieces are imported lazily so the C-ABI can be inspected without torch
-    if name in ("BatchOptimization", "BatchSimulator", "BatchOutputs", "dynamics_batch", "rk4_batch"):
+    if name in ("BatchOptimization", "BatchSimulator", "BatchOutputs", "ClosedLoop", "dynamics_batch", "rk4_batch"):
         from . import batch
         return getattr(batch, name)
     raise AttributeError(name)

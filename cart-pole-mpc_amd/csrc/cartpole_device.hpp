@@ -596,6 +596,11 @@ __device__ __forceinline__ void sincos_from_base(const TrigBase<R>& tb, const R 
   if (__builtin_expect(!(Math<R>::fabs(d) <= R(1)), 0)) Math<R>::sincos(th, s, c);
 #endif
 }
+// 0 (default): stage 1 of every RK4 step evaluates sine and cosine in full.  1: stage 1 rotates from the previous step's
+// pair when there is one (round 3: the branch on the loop-carried flag and the second code path cost more than the 19
+// instructions saved, 48.9 against 49.9 M re-plans/s).  2 (round 5): the same, and the fused kernel's two rollouts evaluate
+// the base in full BEFORE their loops (Model::chain_begin), so that inside them the flag is a constant and stage 1 is
+// always a rotation -- no branch, one code path.
 #ifndef CPMPC_F64_TRIG_CHAIN
 #define CPMPC_F64_TRIG_CHAIN 0
 #endif

@@ -130,7 +130,8 @@ static inline bool fused_static(int L, int SP) {  // the default horizon's spaci
 // ... and a run-time-spacing variant (dynamic LDS) for any other spacing with one of these interval counts whose
 // per-wave LDS (80 scalars per lane and control for NX = 4) fits the 64 KB a dynamic allocation may take
 static inline size_t fused_dyn_bytes(const cpmpc_solver* s) {
-  const size_t g_bytes = ((size_t)s->NX * s->esize + 15) / 16 * 16;  // a column of Gamma in 16-byte pieces (mpc_fused.hpp)
+  const size_t col = (size_t)s->NX * s->esize;
+  const size_t g_bytes = col % 16 == 0 ? col : (col + 7) / 8 * 8;  // a column of Gamma in 16- or 8-byte pieces (mpc_fused.hpp)
   return (size_t)s->SP * 64 * (4 * (size_t)s->esize + g_bytes);
 }
 static inline bool fused_dynamic(const cpmpc_solver* s) {
@@ -143,8 +144,9 @@ static inline bool fused_built(const cpmpc_solver* s) { return fused_static(s->S
 // LDS a wave of the fused kernel takes for this handle (mpc_fused.hpp: u, du, (U^-1 g), 1/d per control and lane plus a
 // column of Gamma in 16-byte pieces; the slim layout of the double 6-state kernel keeps u, du and Gamma only)
 static inline size_t fused_wave_lds_bytes(const cpmpc_solver* s) {
-  const size_t g_bytes = ((size_t)s->NX * s->esize + 15) / 16 * 16;
-  const bool slim = s->esize == 8 && s->NX > 4 && !s->refine_qp && s->SP <= 10 && fused_static(s->S - 1, s->SP);
+  const size_t col = (size_t)s->NX * s->esize;
+  const size_t g_bytes = col % 16 == 0 ? col : (col + 7) / 8 * 8;
+  const bool slim = s->NX > 4 && !(s->esize == 8 && s->refine_qp) && s->SP <= 10 && fused_static(s->S - 1, s->SP);
   return (size_t)s->SP * 64 * ((slim ? 2 : 4) * (size_t)s->esize + g_bytes);
 }
 

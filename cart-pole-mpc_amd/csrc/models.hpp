@@ -42,6 +42,14 @@ struct SingleModelHandWritten {
   }
   // the same at stage STAGE (1..4) of an RK4 step, with what the stages can share (the pole angle's sine and cosine)
   using StepCache = TrigBase<R>;
+  // before the first step of a rollout from x (CPMPC_F64_TRIG_CHAIN = 2: the base pair in full, once per rollout)
+  __device__ __forceinline__ static void chain_begin(StepCache& sc, const R (&x)[NX]) {
+    if constexpr (Math<R>::kIncrementalTrig && CPMPC_F64_TRIG_CHAIN == 2) {
+      Math<R>::sincos(x[1], sc.s0, sc.c0);
+      sc.th0 = x[1];
+      sc.valid = true;
+    }
+  }
   template <bool WITH_J, bool HAS_EXT, int STAGE>
   __device__ __forceinline__ static void accel_stage(const Consts& k, const R (&x)[NX], const R u,
                                                      const ExtForce<R>& fe, R (&a)[NQ], R (&Ja)[NQ][NX],
@@ -76,6 +84,7 @@ struct SingleModelGenerated {
       single_pendulum_gen_accel_noext<R, WITH_J>(k, x[0], x[1], x[2], x[3], u, R(0), R(0), R(0), a, Ja, Jua);
   }
   using StepCache = NoStepCache;
+  __device__ __forceinline__ static void chain_begin(StepCache&, const R (&)[NX]) {}
   template <bool WITH_J, bool HAS_EXT, int STAGE>
   __device__ __forceinline__ static void accel_stage(const Consts& k, const R (&x)[NX], const R u,
                                                      const ExtForce<R>& fe, R (&a)[NQ], R (&Ja)[NQ][NX],
@@ -161,6 +170,7 @@ struct DoubleModel {
     }
   }
   using StepCache = NoStepCache;
+  __device__ __forceinline__ static void chain_begin(StepCache&, const R (&)[NX]) {}
   template <bool WITH_J, bool HAS_EXT, int STAGE>
   __device__ __forceinline__ static void accel_stage(const Consts& k, const R (&x)[NX], const R u,
                                                      const ExtForce<R>& fe, R (&a)[NQ], R (&Ja)[NQ][NX],
@@ -404,6 +414,124 @@ __device__ __forceinline__ void rk4_step_jac_m(const typename M::Consts& k, cons
     const R v1 = x[NQ + i];
     x[i] += h6 * (v1 + v2[i] * R(2) + v3[i] * R(2) + v4[i]);
     x[NQ + i] += h6 * (a1[i] + a2[i] * R(2) + a3[i] * R(2) + a4[i]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same sensitivities WITHOUT forming A (round 5, the 6-state model in the fused kernel).  rk4_step_jac_m holds three
+// NX x NX blocks (D_j, D_{j+1}, their weighted sum) next to the stage Jacobian while it builds A, and the caller a fourth
+// and fifth (Phi and A Phi): with NX = 6 that is ~180 values live at the peak, more than the float kernel's 256-register
+// budget for two waves per SIMD allows and, in double, the source of a third of the step's instructions
+// (accumulation-register traffic of the spills).  Here the step keeps only what the chain rule needs -- the four stage
+// Jacobians Ja_j (NQ x NX) and Jua_j (NQ) -- and every direction is then pushed through the four stages ON ITS OWN:
+//     w_j = Ja_j z_{j-1} (+ Jua_j),   z_0 = v,   z_j = v + a_j [ (z_{j-1})_bottom ; w_j ],   a = {h/2, h/2, h}
+//     v+_top    = v_top + h v_bottom + h^2/6 (w_1 + w_2 + w_3)
+//     v+_bottom = v_bottom + h/6 (w_1 + 2 w_2 + 2 w_3 + w_4)
+// (the top NQ rows of K z are the bottom rows of z, so only the bottoms w_j are ever computed).  The columns of Phi, the
+// earlier columns of Gamma and the new column B (v = 0, w_j += Jua_j) are such directions: ~110 multiply-adds each instead
+// of 36 for a product with a formed A, 84 + 21 live values instead of ~180.  Same mathematics as integration.hpp:36-46,
+// another order of the sums.
+// ------------------------------------------------------------------------------------------------
+template <typename R, typename M, bool HAS_EXT>
+__device__ __forceinline__ void rk4_step_stages_m(const typename M::Consts& k, const R h, R (&x)[M::NX], const R u,
+                                                  const ExtForce<R>& fe, R (&JaS)[4][M::NQ][M::NX], R (&JuaS)[4][M::NQ],
+                                                  typename M::StepCache& sc) {
+  constexpr int NX = M::NX, NQ = M::NQ;
+  R a1[NQ], a2[NQ], a3[NQ], a4[NQ], v2[NQ], v3[NQ], v4[NQ], xt[NX];
+  const R hh = h / R(2);
+  M::template accel_stage<true, HAS_EXT, 1>(k, x, u, fe, a1, JaS[0], JuaS[0], sc);
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    v2[i] = x[NQ + i] + a1[i] * hh;
+    xt[i] = x[i] + x[NQ + i] * hh;
+    xt[NQ + i] = v2[i];
+  }
+  M::template accel_stage<true, HAS_EXT, 2>(k, xt, u, fe, a2, JaS[1], JuaS[1], sc);
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    v3[i] = x[NQ + i] + a2[i] * hh;
+    xt[i] = x[i] + v2[i] * hh;
+    xt[NQ + i] = v3[i];
+  }
+  M::template accel_stage<true, HAS_EXT, 3>(k, xt, u, fe, a3, JaS[2], JuaS[2], sc);
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    v4[i] = x[NQ + i] + a3[i] * h;
+    xt[i] = x[i] + v3[i] * h;
+    xt[NQ + i] = v4[i];
+  }
+  M::template accel_stage<true, HAS_EXT, 4>(k, xt, u, fe, a4, JaS[3], JuaS[3], sc);
+  const R h6 = h / R(6);
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const R v1 = x[NQ + i];
+    x[i] += h6 * (v1 + v2[i] * R(2) + v3[i] * R(2) + v4[i]);
+    x[NQ + i] += h6 * (a1[i] + a2[i] * R(2) + a3[i] * R(2) + a4[i]);
+  }
+}
+
+// one direction through the four stages, in place.  WITH_U: the direction of the control (v = 0 on entry is assumed and v
+// is overwritten with B = dx+/du).
+template <typename R, int NX, int NQ, bool WITH_U>
+__device__ __forceinline__ void rk4_push_direction(const R (&JaS)[4][NQ][NX], const R (&JuaS)[4][NQ], const R h, R (&v)[NX]) {
+  const R hh = h / R(2);
+  R zt[NQ], zb[NQ], w[NQ], s3[NQ], s6[NQ];  // z_{j-1} (top, bottom), w_j, w_1 + w_2 + w_3, w_1 + 2 w_2 + 2 w_3 + w_4
+  // stage 1: z_0 = v
+#pragma unroll
+  for (int r = 0; r < NQ; ++r) {
+    if constexpr (WITH_U) {
+      w[r] = JuaS[0][r];
+    } else {
+      R acc = JaS[0][r][0] * v[0];
+#pragma unroll
+      for (int c = 1; c < NX; ++c) acc += JaS[0][r][c] * v[c];
+      w[r] = acc;
+    }
+    s3[r] = w[r];
+    s6[r] = w[r];
+  }
+  // stages 2 .. 4
+#pragma unroll
+  for (int j = 1; j < 4; ++j) {
+    const R a = (j == 3) ? h : hh;
+#pragma unroll
+    for (int r = 0; r < NQ; ++r) {
+      if constexpr (WITH_U) {
+        zt[r] = (j == 1) ? R(0) : a * zb[r];  // (z_0)_bottom = 0
+      } else {
+        zt[r] = v[r] + a * ((j == 1) ? v[NQ + r] : zb[r]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < NQ; ++r) zb[r] = WITH_U ? a * w[r] : v[NQ + r] + a * w[r];
+#pragma unroll
+    for (int r = 0; r < NQ; ++r) {
+      R acc = JaS[j][r][NQ] * zb[0];
+#pragma unroll
+      for (int c = 1; c < NQ; ++c) acc += JaS[j][r][NQ + c] * zb[c];
+      if (!(WITH_U && j == 1)) {  // (z_1)_top = 0 for the control's direction
+#pragma unroll
+        for (int c = 0; c < NQ; ++c) acc += JaS[j][r][c] * zt[c];
+      }
+      if constexpr (WITH_U) acc += JuaS[j][r];
+      w[r] = acc;
+    }
+#pragma unroll
+    for (int r = 0; r < NQ; ++r) {
+      if (j < 3) s3[r] += w[r];
+      s6[r] += (j < 3) ? w[r] * R(2) : w[r];
+    }
+  }
+  const R h6 = h / R(6), hh6 = h * h6;
+#pragma unroll
+  for (int r = 0; r < NQ; ++r) {
+    if constexpr (WITH_U) {
+      v[r] = hh6 * s3[r];
+      v[NQ + r] = h6 * s6[r];
+    } else {
+      v[r] = (v[r] + h * v[NQ + r]) + hh6 * s3[r];
+      v[NQ + r] = v[NQ + r] + h6 * s6[r];
+    }
   }
 }
 

@@ -199,6 +199,11 @@ __device__ __forceinline__ R group_last(R v, int gbase) {
 #ifndef CPMPC_EXIT_FLOOR_F64
 #define CPMPC_EXIT_FLOOR_F64 0
 #endif
+// 1 (default): the linearisation of the 6-state model pushes every direction (the columns of Phi and Gamma, B) through the
+// four RK4 stages on its own instead of forming A and multiplying (models.hpp: rk4_step_stages_m / rk4_push_direction)
+#ifndef CPMPC_FUSED_COLUMNWISE
+#define CPMPC_FUSED_COLUMNWISE 0
+#endif
 #ifndef CPMPC_SWEEP_UNROLL
 #define CPMPC_SWEEP_UNROLL 5
 #endif
@@ -275,15 +280,21 @@ __host__ __device__ constexpr bool fused_lean() {
 // layout above) and the 1/d_k of a lane's controls in registers, a wave needs u + du + Gamma = (8 + 8 + 48) x SP x 64 bytes
 // = 40 KB at SP = 10 instead of 60 KB: four waves per CU -- one per SIMD, all the 512-register kernel can use -- instead of
 // two.  Not for the REFINE instantiation (its second solve needs gw and du side by side).
+// The float kernel of the 6-state model takes the same layout (with 24-byte Gamma columns: 320 B per lane, 20 KB per wave,
+// eight waves per CU) AND a register budget of 256, so that two of its waves share a SIMD like the 4-state float kernel's
+// do (CPMPC_FUSED_SLIM_F32_NX6; one wave issues an instruction every 5.1 cycles at best, a SIMD takes one every 2).
 #ifndef CPMPC_FUSED_SLIM_F64_NX6
 #define CPMPC_FUSED_SLIM_F64_NX6 1
 #endif
+#ifndef CPMPC_FUSED_SLIM_F32_NX6
+#define CPMPC_FUSED_SLIM_F32_NX6 0
+#endif
 template <typename R, typename M, int SP, bool REFINE>
 __host__ __device__ constexpr bool fused_slim() {
-  return CPMPC_FUSED_SLIM_F64_NX6 && sizeof(R) == 8 && M::NX > 4 && !REFINE && SP <= 10;
+  return (sizeof(R) == 8 ? CPMPC_FUSED_SLIM_F64_NX6 : CPMPC_FUSED_SLIM_F32_NX6) && M::NX > 4 && !REFINE && SP <= 10;
 }
 #undef CPMPC_FUSED_BOUNDS
-#define CPMPC_FUSED_BOUNDS_S __launch_bounds__(64, (fused_lean<R, M, SP>() ? 3 : ((sizeof(R) == 4 && M::NX <= 4) ? CPMPC_FUSED_WAVES_F32 : 1)))
+#define CPMPC_FUSED_BOUNDS_S __launch_bounds__(64, (fused_lean<R, M, SP>() ? 3 : ((sizeof(R) == 4 && (M::NX <= 4 || fused_slim<R, M, SP, REFINE>())) ? CPMPC_FUSED_WAVES_F32 : 1)))
 #define CPMPC_FUSED_BOUNDS __launch_bounds__(64, ((sizeof(R) == 4 && M::NX <= 4) ? CPMPC_FUSED_WAVES_F32 : 1))
 
 // ---- Gamma in LDS ---------------------------------------------------------------------------------------------------
@@ -301,33 +312,48 @@ __host__ __device__ constexpr bool fused_slim() {
 #ifndef CPMPC_FUSED_G_PLANES
 #define CPMPC_FUSED_G_PLANES 0
 #endif
-struct alignas(16) GPiece {
-  unsigned w[4];
-};
-// Round 5: a column occupies only the 16-byte pieces it fills -- 48 bytes instead of the padded 64 for double / NX = 6
-// (CPMPC_FUSED_G_UNPADDED = 0 restores the padded element): Gamma is 30 KB instead of 40 KB per wave there, the kernel's
-// LDS 50 KB instead of 60 KB, three waves per CU instead of two.  Float / NX = 6 (24 bytes) still takes two pieces.
+// Round 5: a column occupies only the pieces it fills -- 48 bytes instead of the padded 64 for double / NX = 6, 24 instead of
+// 32 for float / NX = 6 (CPMPC_FUSED_G_UNPADDED = 0 restores the padded elements): Gamma is 30 KB instead of 40 KB per wave
+// for the double 6-state kernel, three waves per CU instead of two (and four with the slim layout below).
 #ifndef CPMPC_FUSED_G_UNPADDED
 #define CPMPC_FUSED_G_UNPADDED 1
 #endif
+// A piece is 16 bytes where the column is a whole number of them (float / NX = 4: one; double / NX = 4: two; double /
+// NX = 6: three) and 8 bytes otherwise (float / NX = 6: 24 bytes = three pieces of 8 instead of the padded 32: 15 KB of Gamma
+// per wave instead of 20, which is what lets the float 6-state kernel's LDS fit eight waves per CU, round 5).
+template <int BYTES>
+struct alignas(BYTES) GPieceT {
+  unsigned w[BYTES / 4];
+};
 template <typename R, int NX>
-__host__ __device__ constexpr int fused_g_pieces() {
-  return CPMPC_FUSED_G_UNPADDED ? (int)((NX * sizeof(R) + 15) / 16) : (int)(sizeof(XV<R, NX>) / 16);
+__host__ __device__ constexpr int fused_g_piece_bytes() {
+  return (CPMPC_FUSED_G_UNPADDED && (NX * sizeof(R)) % 16 != 0) ? 8 : 16;
 }
 template <typename R, int NX>
-__device__ __forceinline__ XV<R, NX> fused_g_ld(const GPiece* g, int i, int lane) {
+using GPieceOf = GPieceT<fused_g_piece_bytes<R, NX>()>;
+template <typename R, int NX>
+__host__ __device__ constexpr int fused_g_pieces() {
+  constexpr int PB = fused_g_piece_bytes<R, NX>();
+  return CPMPC_FUSED_G_UNPADDED ? (int)((NX * sizeof(R) + PB - 1) / PB) : (int)(sizeof(XV<R, NX>) / 16);
+}
+template <typename R, int NX>
+__host__ __device__ constexpr size_t fused_g_bytes() {  // LDS bytes of one column
+  return (size_t)fused_g_pieces<R, NX>() * fused_g_piece_bytes<R, NX>();
+}
+template <typename R, int NX>
+__device__ __forceinline__ XV<R, NX> fused_g_ld(const GPieceOf<R, NX>* g, int i, int lane) {
   constexpr int K = fused_g_pieces<R, NX>();
   XV<R, NX> v;
-  GPiece pc[K];
+  GPieceOf<R, NX> pc[K];
 #pragma unroll
   for (int p = 0; p < K; ++p) pc[p] = CPMPC_FUSED_G_PLANES ? g[(i * K + p) * 64 + lane] : g[(i * 64 + lane) * K + p];
   __builtin_memcpy(&v, pc, sizeof pc <= sizeof v ? sizeof pc : sizeof v);  // (the padding of v, if any, is never read)
   return v;
 }
 template <typename R, int NX>
-__device__ __forceinline__ void fused_g_st(GPiece* g, int i, int lane, const XV<R, NX> v) {
+__device__ __forceinline__ void fused_g_st(GPieceOf<R, NX>* g, int i, int lane, const XV<R, NX> v) {
   constexpr int K = fused_g_pieces<R, NX>();
-  GPiece pc[K];
+  GPieceOf<R, NX> pc[K];
   __builtin_memcpy(pc, &v, sizeof pc <= sizeof v ? sizeof pc : sizeof v);
 #pragma unroll
   for (int p = 0; p < K; ++p) {
@@ -347,7 +373,7 @@ __global__ CPMPC_FUSED_BOUNDS_S CPMPC_FUSED_EXTRA_ATTR void fused_sqp_kernel(con
   constexpr bool kLean = fused_lean<R, M, SP>() || kSlim;
   __shared__ R lds_u[SP * 64];
   __shared__ R lds_du[SP * 64];
-  __shared__ GPiece lds_G[SP * 64 * fused_g_pieces<R, NX>()];  // column i of my Gamma_s (fused_g_ld / fused_g_st)
+  __shared__ GPieceOf<R, NX> lds_G[SP * 64 * fused_g_pieces<R, NX>()];  // column i of my Gamma_s (fused_g_ld / fused_g_st)
   __shared__ R lds_gw_own[kLean ? 1 : SP * 64];  // (U^-1 g)_k of my controls
 #ifndef CPMPC_FUSED_ID_REGS
 #define CPMPC_FUSED_ID_REGS 0  // 1: 1/d_k in registers (15 KB of LDS, but the full unroll it needs spills 151 values: slower)
@@ -383,7 +409,7 @@ __global__ CPMPC_FUSED_BOUNDS_S CPMPC_FUSED_EXTRA_ATTR void fused_sqp_kernel(con
 // carved from dynamic shared memory (fused_dyn_lds_bytes), the matrix powers use a run-time exponent.
 template <typename R, typename M>
 __host__ __device__ constexpr size_t fused_dyn_lds_bytes(int sp) {
-  return (size_t)sp * 64 * (4 * sizeof(R) + 16 * (size_t)fused_g_pieces<R, M::NX>());
+  return (size_t)sp * 64 * (4 * sizeof(R) + fused_g_bytes<R, M::NX>());
 }
 template <typename R, typename M, int L, bool SHARED, bool REFINE>
 __global__ CPMPC_FUSED_BOUNDS void fused_sqp_dyn_kernel(const SolverArgs<R, M> a, const int max_iters) {
@@ -391,7 +417,7 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_dyn_kernel(const SolverArgs<R, M> a
   constexpr int PPW = 64 / L;
   const int SP = a.SP;
   extern __shared__ __align__(32) unsigned char fused_dyn_lds[];
-  GPiece* lds_G = reinterpret_cast<GPiece*>(fused_dyn_lds);   // widest elements first: stays aligned
+  GPieceOf<R, NX>* lds_G = reinterpret_cast<GPieceOf<R, NX>*>(fused_dyn_lds);   // widest elements first: stays aligned
   R* lds_u = reinterpret_cast<R*>(lds_G + (size_t)SP * 64 * fused_g_pieces<R, NX>());
   R* lds_du = lds_u + (size_t)SP * 64;
   R* lds_gw = lds_du + (size_t)SP * 64;

@@ -172,3 +172,26 @@ def test_poisoned_settled_controllers_leave_with_non_finite_and_keep_their_plan(
         oc.set_previous_solution(z_before[:, i].double().cpu().numpy())
         so = oc.step(x_bad[:, i].double().cpu().numpy(), dyn_bad[:, i].double().cpu().numpy(), 0.0)
         assert so.solver_outputs.termination_state == orc.TERM_NON_FINITE, i
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_closed_loop_as_column_ranges_is_bitwise_the_single_range(pkg, dtype):
+    """pkg.ClosedLoop(ranges = n): the batch held as n independent column ranges (own handle, plant and stream each, no
+    synchronisation between them) gives bit for bit the controls, iteration counts and plant states of one range, tick after
+    tick -- through a transient (controllers start up to 0.4 rad from upright) with ragged range sizes (B = 4099, 3 ranges)."""
+    rng = np.random.default_rng(12)
+    B = 4099
+    xs = np.stack([rng.uniform(-0.3, 0.3, B), np.pi / 2 + rng.uniform(-0.4, 0.4, B), rng.uniform(-0.5, 0.5, B), rng.uniform(-1, 1, B)])
+    one = pkg.ClosedLoop(pkg.default_params(), B, dtype=dtype, device=0, ranges=1)
+    three = pkg.ClosedLoop(pkg.default_params(), B, dtype=dtype, device=0, ranges=3)
+    assert three.bounds == [0, 1366, 2732, 4099]
+    for loop in (one, three):
+        loop.set_state(T(xs, dtype))
+    for k in range(40):
+        one.tick(DYN_UI, 0.0)
+        three.tick(DYN_UI, 0.0)
+        if k % 13 == 0 or k == 39:
+            assert torch.equal(one.controls(), three.controls()), k
+            assert torch.equal(one.iterations(), three.iterations()) and torch.equal(one.status(), three.status()), k
+            assert torch.equal(one.state(), three.state()), k
+    assert one.iterations().float().mean().item() > 1.0   # still in the transient: the ranges were not trivially idle
