@@ -543,6 +543,10 @@ def variants(torch, pkg, args, tdt, dev, local_rank, x0, B):
             sim.step(DYN_UI, 0.01, o.u[0].contiguous())
         its = 0.0
         quiesce(torch)
+        for _ in range(10 if settle else 0):   # a settled loop: a few more untimed ticks between the collection and the clock
+            o = opt.step(sim.get_state(), DYN_UI, 0.0, want_predicted=False, want_stats=True, out=out)
+            sim.step(DYN_UI, 0.01, o.u[0].contiguous())
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         for k in range(ticks):
             o = opt.step(sim.get_state(), DYN_UI, 0.0, want_predicted=False, want_stats=True, out=out)
@@ -814,9 +818,11 @@ def split_streams_variant(torch, pkg, args, dev, local_rank, B, steps=20):
     batch held by 2 / 4 handles of B / parts problems, each stepped on its own stream with no synchronisation between the
     shards.  A step is prepare (HBM-bound) -> fused SQP kernel (issue-bound, ending in a tail of partly filled compute
     units) -> finalize (HBM-bound); free-running shards drift apart, so the memory-bound kernels and the tail of one shard
-    overlap the arithmetic of another.  (Splitting ONE step into column ranges that fork from and join the caller's
-    stream was built and measured in round 4: +0.2 % fp64, -1.5..-5 % fp32 -- ranges that start together reach every phase
-    together -- and removed; the gain needs the shards to be independent across steps, which separate handles give.)
+    can overlap the arithmetic of another.  Measured: within +-3 % of the single handle in either dtype (profiles/r04_bench.json,
+    r05_bench.json) -- nothing reliable for this workload, where prepare + finalize are 6 % of a step; the settled closed loop,
+    where they and the plant are a quarter of a tick, does gain (closed_loop_ranges).  (Splitting ONE step into column
+    ranges that fork from and join the caller's stream was built and measured in round 4: +0.2 % fp64, -1.5..-5 % fp32 --
+    ranges that start together reach every phase together -- and removed.)
     Wall-clock re-plans/s per setting and that the controls are bitwise those of the single handle."""
     over = dict(max_iterations=args.iters, relative_exit_tol=0.0, absolute_first_derivative_tol=0.0)
     x_np = synth_states(SEED, B)
@@ -839,9 +845,10 @@ def split_streams_variant(torch, pkg, args, dev, local_rank, B, steps=20):
                         o.reset()
                         o.step(x, DYN_UI, 0.0, want_predicted=True, out=out)
 
-            for _ in range(3):
+            quiesce(torch)   # (collect first: the steps after a long idle gap run slower, see timed_region)
+            for _ in range(8):
                 step()
-            quiesce(torch)
+            torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(steps):
                 step()
