@@ -546,3 +546,8 @@ def test_bench_with_four_ranks_on_the_one_gpu():
     assert line["n_gpus"] == 4 and d["world_size_seen"] == 4 and d["spawned_by_bench"]
     assert line["gathered"]["shape"] == [40, 4 * 4096] and line["gathered"]["own_block_intact"]
     assert all(len(v) == 4 for k, v in d["per_rank"].items() if isinstance(v, list))
+    # round 5: every rank reports its device, backend and peer-access row before the timed region; the launcher relays it
+    for rk in range(4):
+        rep = [ln for ln in r.stderr.splitlines() if ln.startswith("[rank %d] bench.py rank %d/4: device 0 of 1 visible" % (rk, rk))]
+        assert len(rep) == 1 and "process group gloo world 4" in rep[0] and "peer access to devices [-]" in rep[0], r.stderr[-3000:]
+    assert line["preheated"] and line["preheat_steps"] >= 32

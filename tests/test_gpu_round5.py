@@ -195,3 +195,31 @@ def test_closed_loop_as_column_ranges_is_bitwise_the_single_range(pkg, dtype):
             assert torch.equal(one.iterations(), three.iterations()) and torch.equal(one.status(), three.status()), k
             assert torch.equal(one.state(), three.state()), k
     assert one.iterations().float().mean().item() > 1.0   # still in the transient: the ranges were not trivially idle
+
+
+def test_plain_sqp_tool_reports_both_phases_in_both_dtypes():
+    """tools/plain_sqp.py (bench.py variants.plain_sqp runs it in child processes) at unit-test size: the specification as
+    shipped against the iteration without the full-step rule and the exit floor (the -DCPMPC_SKIP_MERIT=0 library is the
+    third switch; here the product library serves both runs).  Settled float controllers: fewer iterations per tick with the
+    floor than without; no solver failure anywhere."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    tool = os.path.join(ROOT, "tools", "plain_sqp.py")
+    env = {k: v for k, v in os.environ.items() if k != "CPMPC_LIB"}
+    res = {}
+    for name, extra in (("defaults", []), ("plain", ["--full-step-below", "0", "--exit-defect-floor", "0"])):
+        r = subprocess.run([sys.executable, tool, "--batch", "4096", "--ticks", "260", "--settled", "20"] + extra, env=env,
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[name] = json.loads(r.stdout.strip().splitlines()[-1])
+    for name, d in res.items():
+        for dt in ("f32", "f64"):
+            for phase in ("soak", "settled"):
+                assert d[dt][phase]["solver_failures"] == 0, (name, dt, phase)
+            assert d[dt]["settled"]["pole_error_median"] < 1e-4   # (2.8 s after a start from anywhere: upright, still settling)
+    assert res["defaults"]["exit_defect_floor"] == 2.0 and res["plain"]["exit_defect_floor"] == 0.0
+    assert res["defaults"]["f32"]["settled"]["iterations_per_tick"] + 0.5 < res["plain"]["f32"]["settled"]["iterations_per_tick"]
+    assert abs(res["defaults"]["f64"]["settled"]["iterations_per_tick"] - res["plain"]["f64"]["settled"]["iterations_per_tick"]) < 0.1
