@@ -146,7 +146,8 @@ static inline bool fused_built(const cpmpc_solver* s) { return fused_static(s->S
 static inline size_t fused_wave_lds_bytes(const cpmpc_solver* s) {
   const size_t col = (size_t)s->NX * s->esize;
   const size_t g_bytes = col % 16 == 0 ? col : (col + 7) / 8 * 8;
-  const bool slim = s->NX > 4 && !(s->esize == 8 && s->refine_qp) && s->SP <= 10 && fused_static(s->S - 1, s->SP);
+  // (the slim layout is the double 6-state kernel's: mpc_fused.hpp, CPMPC_FUSED_SLIM_F64_NX6 = 1, ..._F32_NX6 = 0)
+  const bool slim = s->esize == 8 && s->NX > 4 && !s->refine_qp && s->SP <= 10 && fused_static(s->S - 1, s->SP);
   return (size_t)s->SP * 64 * ((slim ? 2 : 4) * (size_t)s->esize + g_bytes);
 }
 
