@@ -214,3 +214,32 @@ def test_config5_full_size(pkg, orc):
     far = samp >= h
     print("config 5: fp64 |du| max %.2e median %.2e (near upright max %.2e, within 0.5 rad max %.2e);  fp32 median %.2e"
           % (err.max(), np.median(err), err[~far].max(), err[far].max(), np.median(e32)))
+
+
+@pytest.mark.parametrize("N,sp,refine", [(40, 10, None), (40, 10, True), (40, 5, None), (20, 10, None), (20, 5, None), (40, 8, None),
+                                          (40, 4, None), (40, 20, None), (30, 6, None), (30, 3, None)])
+def test_double_fused_layouts_across_shapes(pkg, orc, N, sp, refine):
+    """The LDS layouts of the double 6-state fused kernel (round 5) over every compiled (intervals, spacing) pair and the
+    run-time-spacing kernel: slim (u, du, 48-byte Gamma columns; 1/d_k in registers) for spacings up to 10, the four-array
+    layout for the REFINE instantiation and for spacing 20 (100 KB per wave: AUTO would take the split pipeline, here the fused
+    one is forced), dynamic LDS for spacings without a specialisation.  192 lanes within 0.15 rad of upright, 4 iterations,
+    exits disabled: same termination state and iteration count as the oracle, controls within 1e-5 on every lane; the fused
+    and the split pipeline agree to 1e-7."""
+    rng = np.random.default_rng(100 * N + sp)
+    B = 192
+    x0 = near_upright(rng, B)
+    over = dict(OVER, window_length=N, state_spacing=sp, max_iterations=4, relative_exit_tol=0.0, absolute_first_derivative_tol=0.0)
+    u_cpu, _, st_cpu, it_cpu, _ = orc.step_batch_cold(orc.default_opt_params(**over), DYN, 0.03, x0, model="double")
+    res = {}
+    for pipeline in ("fused", "split"):
+        opt = pkg.BatchOptimization(pkg.default_params(**over), max_batch=B, dtype=torch.float64, device=0, model="double",
+                                    refine_qp=refine)
+        opt.set_pipeline(pipeline)
+        assert opt.pipeline() == pipeline
+        out = opt.step(T(x0), DYN, 0.03)
+        u = N_(out.u)
+        err = np.abs(u - u_cpu).max(axis=0)
+        assert (N_(out.status) == st_cpu).all() and (N_(out.iterations) == it_cpu).all(), (pipeline, N, sp)
+        assert err.max() < 1e-5, (pipeline, N, sp, np.sort(err)[-3:])
+        res[pipeline] = u
+    assert np.abs(res["fused"] - res["split"]).max() < 1e-7
