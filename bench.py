@@ -590,6 +590,11 @@ def variants(torch, pkg, args, tdt, dev, local_rank, x0, B):
         res["per_problem_params"] = per_problem_variant(torch, pkg, args, dev, local_rank, B)
     except Exception as exc:  # noqa: BLE001
         res["per_problem_params"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    if tdt == torch.float32:
+        try:
+            res["wide_qp_f32"] = wide_qp_variant(torch, pkg, args, dev, local_rank, B)
+        except Exception as exc:  # noqa: BLE001
+            res["wide_qp_f32"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     try:
         res["double_pendulum"] = double_pendulum_variant(torch, pkg, args, dev, local_rank)
     except Exception as exc:  # noqa: BLE001
@@ -675,6 +680,53 @@ def per_problem_variant(torch, pkg, args, dev, local_rank, B, lanes=4096, steps=
         rec["parity_vs_cpu_check"] = ps
         res[name] = rec
         del opt
+    return res
+
+
+def wide_qp_variant(torch, pkg, args, dev, local_rank, B, lanes=8192, steps=20):
+    """The headline's workload on a CPMPC_CREATE_WIDE_QP handle (float kernels that carry the whole terminal part of the QP in
+    double, not only the NX x NX system) next to the default float handle: re-plans/s (the faster of two runs of `steps`), the
+    fused kernel's HIP-event time, and the controls of `lanes` problems against the double CPU check -- what the option costs
+    and what it buys."""
+    from oracle import oracle as orc
+    over = dict(max_iterations=args.iters, relative_exit_tol=0.0, absolute_first_derivative_tol=0.0)
+    x_np = synth_states(SEED, B)
+    x0 = torch.tensor(x_np, dtype=torch.float32, device=dev)
+    idx = np.unique(np.linspace(0, B - 1, min(lanes, B)).astype(np.int64))
+    u_c, _, st_c, _, _ = orc.step_batch_cold(orc.default_opt_params(**over), DYN_UI, 0.0, x_np[:, idx])
+    res = {"note": "fp32, B = %d, cold start, %d iterations, exits disabled; parity = max |du| per problem against the double CPU "
+                   "check on %d evenly spaced lanes" % (B, args.iters, idx.size)}
+    for name, wide in (("default", False), ("wide_qp", True)):
+        quiesce(torch)
+        opt = pkg.BatchOptimization(pkg.default_params(**over), max_batch=B, dtype=torch.float32, device=local_rank, wide_qp=wide)
+        opt.set_pipeline(args.pipeline)
+        out = pkg.BatchOutputs()
+        for _ in range(8):
+            opt.reset()
+            opt.step(x0, DYN_UI, 0.0, out=out)
+        torch.cuda.synchronize()
+        opt.profile_enable(True)
+        el, prof = None, None
+        for _ in range(2):
+            opt.profile_reset()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                opt.reset()
+                o = opt.step(x0, DYN_UI, 0.0, out=out)
+            torch.cuda.synchronize()
+            el_k = (time.perf_counter() - t0) / steps
+            if el is None or el_k < el:
+                el, prof = el_k, opt.profile_read()
+        opt.profile_enable(False)
+        u_g = o.u[:, torch.as_tensor(idx, device=dev)].double().cpu().numpy()
+        ps, err = parity_stats(u_g, u_c, o.status.cpu().numpy()[idx], st_c)
+        ps["fraction_within_1e-2"] = float((err < 1e-2).mean())
+        res[name] = {"re-plans/s": B / el, "ms_per_step": el * 1e3, "wide_qp": opt.wide_qp,
+                     "fused_sqp_kernel_ms": round(prof["fused_sqp_kernel"][0] / max(prof["fused_sqp_kernel"][1], 1), 4),
+                     "parity_vs_cpu_check": ps}
+        opt.close()
+        del opt
+    res["throughput_ratio"] = res["wide_qp"]["re-plans/s"] / res["default"]["re-plans/s"]
     return res
 
 

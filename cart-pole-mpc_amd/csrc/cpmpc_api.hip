@@ -175,7 +175,7 @@ static int create_impl(const cpmpc_params* params, const cpmpc_solver_opts* opts
   int rc = validate_params(params);
   if (rc) return rc;
   if ((flags & ~(uint32_t)(CPMPC_CREATE_ALLOW_LONG_HORIZON | CPMPC_CREATE_REFINE_QP | CPMPC_CREATE_NO_REFINE_QP |
-                           CPMPC_CREATE_STRICT_HORIZON)) != 0)
+                           CPMPC_CREATE_STRICT_HORIZON | CPMPC_CREATE_WIDE_QP)) != 0)
     return fail(CPMPC_ERR_INVALID_ARG, "unknown creation flags 0x%x", flags);
   if ((flags & CPMPC_CREATE_REFINE_QP) && (flags & CPMPC_CREATE_NO_REFINE_QP))
     return fail(CPMPC_ERR_INVALID_ARG, "CPMPC_CREATE_REFINE_QP and CPMPC_CREATE_NO_REFINE_QP exclude each other");
@@ -224,6 +224,7 @@ static int create_impl(const cpmpc_params* params, const cpmpc_solver_opts* opts
   // default: refine where the control cost is weak (measured: include/cpmpc.h, CPMPC_CREATE_REFINE_QP)
   s->refine_qp = (flags & CPMPC_CREATE_REFINE_QP) != 0 ||
                  (!(flags & CPMPC_CREATE_NO_REFINE_QP) && params->u_cost_weight < kRefineBelowUCostWeight);
+  s->wide_qp = (flags & CPMPC_CREATE_WIDE_QP) != 0 && dtype == CPMPC_F32 && model == CPMPC_MODEL_SINGLE;
   s->model = model;
   s->device = device;
   s->esize = dtype == CPMPC_F32 ? 4 : 8;
@@ -362,6 +363,9 @@ extern "C" int cpmpc_num_states(const cpmpc_solver* s) { return s ? s->S : -1; }
 extern "C" int cpmpc_dtype(const cpmpc_solver* s) { return s ? s->dtype : -1; }
 extern "C" int cpmpc_model(const cpmpc_solver* s) { return s ? s->model : -1; }
 extern "C" int cpmpc_refines_qp(const cpmpc_solver* s) { return s ? (s->refine_qp && s->dtype == CPMPC_F64 ? 1 : 0) : -1; }
+extern "C" int cpmpc_wide_qp(const cpmpc_solver* s) {
+  return s ? (s->wide_qp && use_fused(s) && fused_static(s->S - 1, s->SP) ? 1 : 0) : -1;
+}
 extern "C" int cpmpc_has_previous_solution(const cpmpc_solver* s) { return (s && s->prev_B > 0) ? 1 : 0; }
 extern "C" int64_t cpmpc_previous_solution_batch(const cpmpc_solver* s) { return s ? s->prev_B : 0; }
 

@@ -133,10 +133,11 @@ static void launch_fused(const SolverArgs<R, M>& a, int L, int SP, int max_iters
   {
     const int ppw = 64 / L;
     const dim3 grid((unsigned)((a.B + ppw - 1) / ppw));
-    // REFINE exists for the double kernels only (constants through vector registers there, SHARED = false)
+    // REFINE = true: the double kernels' refinement of the whole QP solution (CPMPC_CREATE_REFINE_QP), the float 4-state
+    // kernels' QP in double (CPMPC_CREATE_WIDE_QP); constants through vector registers there (SHARED = false)
 #define CPMPC_FUSED(LV, SPV)                                                                                \
   if (L == LV && SP == SPV) {                                                                               \
-    if constexpr (sizeof(R) == 8) {                                                                         \
+    if constexpr (sizeof(R) == 8 || M::NX <= 4) { /* double: REFINE_QP; float, 4-state model: WIDE_QP */   \
       if (refine) {                                                                                         \
         hipLaunchKernelGGL((fused_sqp_kernel<R, M, SPV, LV, false, true>), grid, dim3(64), 0, stream, a, max_iters); \
         return;                                                                                             \
@@ -236,7 +237,7 @@ static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* 
     a.iter_cap = total;
     a.run_out_below = (int64_t)2048 * (64 / (s->S - 1));  // problems in one round of resident waves (2 per SIMD)
     span_begin(s, CPMPC_KERNEL_FUSED, stream, &sp);
-    launch_fused<R, M>(a, s->S - 1, s->SP, bounds[1], s->refine_qp, stream);
+    launch_fused<R, M>(a, s->S - 1, s->SP, bounds[1], sizeof(R) == 8 ? s->refine_qp : s->wide_qp, stream);
     span_end(s, stream, &sp);
     for (int stage = 0; stage + 1 < n_stages; ++stage) {
       const int done = bounds[stage + 1];
@@ -255,7 +256,7 @@ static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* 
       a.active_list = s->active + col0;
       a.active_count = count;
       const int k = bounds[stage + 2] - done;
-      launch_fused<R, M>(a, s->S - 1, s->SP, k, s->refine_qp, stream);
+      launch_fused<R, M>(a, s->S - 1, s->SP, k, sizeof(R) == 8 ? s->refine_qp : s->wide_qp, stream);
       span_end(s, stream, &sp);
     }
   } else {

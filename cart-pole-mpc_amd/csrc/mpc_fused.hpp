@@ -204,6 +204,11 @@ __device__ __forceinline__ R group_last(R v, int gbase) {
 #ifndef CPMPC_FUSED_COLUMNWISE
 #define CPMPC_FUSED_COLUMNWISE 0
 #endif
+// 1: the float 4-state kernels carry the whole terminal part of the QP in double (mpc_fused_body.inc: kWideQP); measured in
+// round 5, see HISTORY.md
+#ifndef CPMPC_FUSED_WIDE_QP_F32
+#define CPMPC_FUSED_WIDE_QP_F32 0
+#endif
 #ifndef CPMPC_SWEEP_UNROLL
 #define CPMPC_SWEEP_UNROLL 5
 #endif
@@ -397,7 +402,9 @@ __global__ CPMPC_FUSED_BOUNDS_S CPMPC_FUSED_EXTRA_ATTR void fused_sqp_kernel(con
     if constexpr (kIdRegs) __builtin_amdgcn_sched_barrier(0);   \
   } while (0)
 #define CPMPC_FUSED_MAT2_POW(T, E) mat2_pow<R, (E)>(T)
+#define CPMPC_FUSED_BODY_DYN 0
 #include "mpc_fused_body.inc"
+#undef CPMPC_FUSED_BODY_DYN
 #undef CPMPC_FUSED_MAT2_POW
 #undef CPMPC_SWEEP_PRAGMA
 #undef CPMPC_SWEEP_FENCE
@@ -427,7 +434,9 @@ __global__ CPMPC_FUSED_BOUNDS void fused_sqp_dyn_kernel(const SolverArgs<R, M> a
 #define CPMPC_SWEEP_PRAGMA _Pragma("unroll 5")
 #define CPMPC_SWEEP_FENCE() do { } while (0)
 #define CPMPC_FUSED_MAT2_POW(T, E) mat2_pow_rt<R>(T, (E))
+#define CPMPC_FUSED_BODY_DYN 1
 #include "mpc_fused_body.inc"
+#undef CPMPC_FUSED_BODY_DYN
 #undef CPMPC_FUSED_MAT2_POW
 #undef CPMPC_SWEEP_PRAGMA
 #undef CPMPC_SWEEP_FENCE
