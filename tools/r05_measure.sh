@@ -4,7 +4,8 @@
 #                          profiles/r05_box_spread.json, plus the 200-step run next to it
 #   r05_measure.sh D       BASELINE configs[4] (double pendulum): rocprofv3 kernel trace + SQ counter passes, both dtypes
 #   r05_measure.sh H       the headline workload: rocprofv3 passes in fp32 and fp64 (tools/prof.sh)
-#   r05_measure.sh B       closed-loop soaks (1000 ticks x 262144, both dtypes) + settled-tick trace
+#   r05_measure.sh B       closed-loop soaks (1000 ticks x 262144, both dtypes)
+#   r05_measure.sh P       parity sweep (GPU fp64 vs the CPU check, eighteen configurations, 1.6 M problems)
 set -uo pipefail
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$R"
@@ -34,5 +35,8 @@ H)
 B)
   python tools/soak.py --dtype f32 --ticks 1000 --out $O/soak_f32.json > $O/soak_f32.log 2>&1; echo "soak f32 rc=$?"
   python tools/soak.py --dtype f64 --ticks 1000 --out $O/soak_f64.json > $O/soak_f64.log 2>&1; echo "soak f64 rc=$?"
+  ;;
+P)
+  python tools/parity_sweep.py $O/parity_sweep.json > $O/parity_sweep.log 2>&1; echo "parity sweep rc=$?"
   ;;
 esac
