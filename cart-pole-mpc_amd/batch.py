@@ -93,15 +93,17 @@ class BatchOptimization:
     """B independent pendulum::Optimization controllers solved in lock-step on one GPU."""
 
     def __init__(self, params, max_batch, dtype=torch.float32, device=None, opts=None, model="single",
-                 allow_long_horizon=False, refine_qp=None, strict_horizon=False, wide_qp=False):
+                 allow_long_horizon=False, refine_qp=None, strict_horizon=False, wide_qp=None):
         """strict_horizon: refuse (CpmpcError(ERR_UNSUPPORTED)) window_length * control_dt beyond
         cpmpc_max_parity_horizon() (1.0 s), where the condensed QP is no longer held to 1e-5 of a full-space solve on
         every problem (include/cpmpc.h, CPMPC_CREATE_STRICT_HORIZON).  By default every horizon the reference accepts is
         accepted, with one warning per process; allow_long_horizon=True silences the warning.
         refine_qp: True / False force on / off the refinement of the whole QP solution in the fp64 fused kernels
         (CPMPC_CREATE_[NO_]REFINE_QP: 7 % slower); None = the library's default: on when u_cost_weight < 0.05.
-        wide_qp: float32 handles of the 4-state model carry the QP's terminal part in double (CPMPC_CREATE_WIDE_QP: cold starts
-        end three (median) to twenty (99th percentile) times closer to the double check for 2.7 % of the throughput)."""
+        wide_qp: True / False force on / off that float32 handles carry the QP's whole terminal part in double
+        (CPMPC_CREATE_[NO_]WIDE_QP: cold starts end where a float solve can -- 3x to 20x closer to the double check for the
+        4-state model at 3.8 % of the throughput, 70x to 900x for the 6-state one at 0 - 5 %); None = the library's
+        default: on for the 6-state model, off for the 4-state one."""
         lib = capi.load()
         self.model = capi.MODELS[model]
         self.nx = lib.cpmpc_model_state_dim(self.model)
@@ -119,7 +121,7 @@ class BatchOptimization:
         info = capi.CreateInfo(struct_size=C.sizeof(capi.CreateInfo),
                                flags=(capi.CREATE_ALLOW_LONG_HORIZON if allow_long_horizon else 0)
                                | (capi.CREATE_STRICT_HORIZON if strict_horizon else 0)
-                               | (capi.CREATE_WIDE_QP if wide_qp else 0)
+                               | (0 if wide_qp is None else (capi.CREATE_WIDE_QP if wide_qp else capi.CREATE_NO_WIDE_QP))
                                | (0 if refine_qp is None else (capi.CREATE_REFINE_QP if refine_qp else capi.CREATE_NO_REFINE_QP)),
                                dtype=_CAPI_DTYPE[dtype], model=self.model, device=self.device, reserved=0,
                                max_batch=self.max_batch, params=C.pointer(params),

@@ -132,6 +132,7 @@ CREATE_REFINE_QP = 2
 CREATE_NO_REFINE_QP = 4
 CREATE_STRICT_HORIZON = 8
 CREATE_WIDE_QP = 16
+CREATE_NO_WIDE_QP = 32
 SOLVER_OPTS_SIZE_POSITIONAL = 128
 
 

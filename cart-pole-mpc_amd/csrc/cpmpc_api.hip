@@ -175,10 +175,12 @@ static int create_impl(const cpmpc_params* params, const cpmpc_solver_opts* opts
   int rc = validate_params(params);
   if (rc) return rc;
   if ((flags & ~(uint32_t)(CPMPC_CREATE_ALLOW_LONG_HORIZON | CPMPC_CREATE_REFINE_QP | CPMPC_CREATE_NO_REFINE_QP |
-                           CPMPC_CREATE_STRICT_HORIZON | CPMPC_CREATE_WIDE_QP)) != 0)
+                           CPMPC_CREATE_STRICT_HORIZON | CPMPC_CREATE_WIDE_QP | CPMPC_CREATE_NO_WIDE_QP)) != 0)
     return fail(CPMPC_ERR_INVALID_ARG, "unknown creation flags 0x%x", flags);
   if ((flags & CPMPC_CREATE_REFINE_QP) && (flags & CPMPC_CREATE_NO_REFINE_QP))
     return fail(CPMPC_ERR_INVALID_ARG, "CPMPC_CREATE_REFINE_QP and CPMPC_CREATE_NO_REFINE_QP exclude each other");
+  if ((flags & CPMPC_CREATE_WIDE_QP) && (flags & CPMPC_CREATE_NO_WIDE_QP))
+    return fail(CPMPC_ERR_INVALID_ARG, "CPMPC_CREATE_WIDE_QP and CPMPC_CREATE_NO_WIDE_QP exclude each other");
   // the struct in some release: the leading int (padded to 8) and a whole number of doubles, from the first release's 13
   // (104 bytes) to this one's; a size that splits a field is nobody's struct
   if (opts != nullptr && (opts_size < 104 || opts_size > sizeof(cpmpc_solver_opts) || opts_size % 8 != 0))
@@ -224,7 +226,9 @@ static int create_impl(const cpmpc_params* params, const cpmpc_solver_opts* opts
   // default: refine where the control cost is weak (measured: include/cpmpc.h, CPMPC_CREATE_REFINE_QP)
   s->refine_qp = (flags & CPMPC_CREATE_REFINE_QP) != 0 ||
                  (!(flags & CPMPC_CREATE_NO_REFINE_QP) && params->u_cost_weight < kRefineBelowUCostWeight);
-  s->wide_qp = (flags & CPMPC_CREATE_WIDE_QP) != 0 && dtype == CPMPC_F32 && model == CPMPC_MODEL_SINGLE;
+  // default: on for the 6-state model (measured: include/cpmpc.h, CPMPC_CREATE_WIDE_QP), off for the 4-state one
+  s->wide_qp = dtype == CPMPC_F32 && ((flags & CPMPC_CREATE_WIDE_QP) != 0 ||
+                                      (!(flags & CPMPC_CREATE_NO_WIDE_QP) && model == CPMPC_MODEL_DOUBLE));
   s->model = model;
   s->device = device;
   s->esize = dtype == CPMPC_F32 ? 4 : 8;

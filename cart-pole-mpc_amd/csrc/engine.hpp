@@ -93,7 +93,7 @@ struct cpmpc_solver {
   int64_t prof_n[CPMPC_KERNEL_COUNT] = {0, 0, 0, 0, 0};
   int pipeline = CPMPC_PIPELINE_AUTO;
   bool refine_qp = false;  // CPMPC_CREATE_REFINE_QP: the double fused kernels refine the whole QP solution once
-  bool wide_qp = false;    // CPMPC_CREATE_WIDE_QP: the float fused kernels (4-state model, compiled spacings) carry the QP's terminal part in double
+  bool wide_qp = false;    // CPMPC_CREATE_WIDE_QP (default for the 6-state model): the float fused kernels (compiled spacings) carry the QP's terminal part in double
   // staged fused pipeline (compaction of the still-active problems between stages); 0/0 = single launch
   // default 2 / 1 (round 4, tools/steady_state.py): in the warm-started closed loop most problems stop after one or two
   // iterations, so compacting after two pays (fp32 at the reference's tolerances 1.47 -> 1.34 ms per tick, the swing-up

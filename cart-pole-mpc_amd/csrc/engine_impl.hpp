@@ -133,11 +133,11 @@ static void launch_fused(const SolverArgs<R, M>& a, int L, int SP, int max_iters
   {
     const int ppw = 64 / L;
     const dim3 grid((unsigned)((a.B + ppw - 1) / ppw));
-    // REFINE = true: the double kernels' refinement of the whole QP solution (CPMPC_CREATE_REFINE_QP), the float 4-state
-    // kernels' QP in double (CPMPC_CREATE_WIDE_QP); constants through vector registers there (SHARED = false)
+    // REFINE = true: the double kernels' refinement of the whole QP solution (CPMPC_CREATE_REFINE_QP), the float kernels'
+    // QP in double (CPMPC_CREATE_WIDE_QP); constants through vector registers there (SHARED = false)
 #define CPMPC_FUSED(LV, SPV)                                                                                \
   if (L == LV && SP == SPV) {                                                                               \
-    if constexpr (sizeof(R) == 8 || M::NX <= 4) { /* double: REFINE_QP; float, 4-state model: WIDE_QP */   \
+    { /* double: REFINE_QP; float: WIDE_QP */                                                               \
       if (refine) {                                                                                         \
         hipLaunchKernelGGL((fused_sqp_kernel<R, M, SPV, LV, false, true>), grid, dim3(64), 0, stream, a, max_iters); \
         return;                                                                                             \

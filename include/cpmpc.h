@@ -175,6 +175,7 @@ void cpmpc_destroy(cpmpc_solver* s);
 #define CPMPC_CREATE_NO_REFINE_QP 4u
 #define CPMPC_CREATE_STRICT_HORIZON 8u
 #define CPMPC_CREATE_WIDE_QP 16u
+#define CPMPC_CREATE_NO_WIDE_QP 32u
 typedef struct cpmpc_create_info {
   uint32_t struct_size; /* = sizeof(cpmpc_create_info) */
   uint32_t flags;
@@ -191,15 +192,22 @@ int cpmpc_create_ex(const cpmpc_create_info* info, cpmpc_solver** out);
 /* bytes of cpmpc_solver_opts the positional constructors read (the struct through full_step_below) */
 #define CPMPC_SOLVER_OPTS_SIZE_POSITIONAL 128u
 int cpmpc_refines_qp(const cpmpc_solver* s); /* 1: this handle's kernels refine the QP solution (CPMPC_CREATE_REFINE_QP) */
-/* CPMPC_CREATE_WIDE_QP (CPMPC_F32 handles of the 4-state model; ignored elsewhere): the fused kernels carry the whole terminal
- * part of the QP in double -- the products of transition matrices across the shooting intervals, the columns of U^-1 R^T,
- * the multipliers and their effect on the step -- not only the NX x NX system.  Measured (round 5, B = 262 144 cold starts,
- * 5 iterations, against the double CPU check, max |du| per problem): median 2.4e-4 -> 8.4e-5, 99th percentile 0.11 ->
- * 4.9e-3, problems within 1e-2: 93.0 % -> 99.5 % -- what a float solve of this algorithm can reach at best (the float build
- * of the CPU check, with its KKT solve in double, ends at 8.0e-5 / 4.9e-3 / 99.3 %) -- for 2.7 % of the cold-start
- * throughput (122.0 -> 118.8 M re-plans/s) and 7 - 9 % of a closed-loop tick, where it changes nothing that matters
- * (warm-started iterations near the optimum: same iteration counts, same final pole error).  Off by default.  Compiled
- * state spacings only (cpmpc_supported_state_spacing() == 2) and the fused pipeline; cpmpc_wide_qp() tells what a handle does. */
+/* CPMPC_CREATE_WIDE_QP / CPMPC_CREATE_NO_WIDE_QP (CPMPC_F32 handles; ignored by CPMPC_F64 ones): force on / off that the fused
+ * kernels carry the whole terminal part of the QP in double -- the products of transition matrices across the shooting
+ * intervals, the columns of U^-1 R^T, the multipliers and their effect on the step -- not only the NX x NX system.  It is
+ * the precision of the QP solve, not the hardware's sin / cos / exp, that separates a float handle from the double CPU
+ * check: with it the kernels end where the float build of that check (its KKT solve in double) ends.  Measured (round 5,
+ * cold starts, 5 iterations, max |du| per problem against the double check: median / 99th percentile / share within 1e-2):
+ *   4-state model, B = 262 144:  2.4e-4 / 0.11 / 93.0 %  ->  8.4e-5 / 4.9e-3 / 99.5 %   (float CPU check 8.0e-5 / 4.9e-3 / 99.3 %)
+ *                                for 3.8 % of the cold-start throughput (122.5 -> 117.9 M re-plans/s) and 7 - 9 % of a
+ *                                closed-loop tick, where it changes nothing that matters (warm-started iterations near the
+ *                                optimum: same iteration counts, same final pole error);
+ *   6-state model, B = 65 536:   4.2e-2 / 8.0 / 19.8 %   ->  5.7e-4 / 9.3e-3 / 99.1 %   (float CPU check 5.2e-4 / 8.7e-3 / 99.2 %)
+ *                                for 0 - 5 % (51.0 -> 50.8 M near upright, 50.9 -> 48.3 M from within 0.5 rad).
+ * DEFAULT (neither flag): ON for the 6-state model -- without it four of five float solves of that model are off by more
+ * than 0.01 N after five iterations -- and OFF for the 4-state one (the reference's model: speed first, the bar of this
+ * path is met by CPMPC_F64 handles).  Compiled state spacings only (cpmpc_supported_state_spacing() == 2) and the fused
+ * pipeline; cpmpc_wide_qp() tells what a handle does. */
 int cpmpc_wide_qp(const cpmpc_solver* s);
 /* seconds: the longest horizon held to 1e-5 of the CPU check on every problem (1.0) */
 double cpmpc_max_parity_horizon(void);

@@ -238,7 +238,7 @@ def test_wide_qp_float_handles_end_where_a_float_solve_can(pkg, orc):
     u64, _, st64, _, _ = orc.step_batch_cold(orc.default_opt_params(**over), DYN_UI, 0.0, x0)
     got = {}
     for wide in (False, True):
-        opt = pkg.BatchOptimization(pkg.default_params(**over), max_batch=B, dtype=torch.float32, device=0, wide_qp=wide)
+        opt = pkg.BatchOptimization(pkg.default_params(**over), max_batch=B, dtype=torch.float32, device=0, wide_qp=wide or None)
         assert opt.wide_qp == wide and opt.pipeline() == "fused"
         o = opt.step(T(x0, torch.float32), DYN_UI, 0.0)
         err = np.abs(o.u.double().cpu().numpy() - u64).max(axis=0)
@@ -260,8 +260,8 @@ def test_wide_qp_float_handles_end_where_a_float_solve_can(pkg, orc):
     assert got[False][0] > 1.5 * got[True][0] and got[False][2] > 5 * got[True][2]
     # ignored where it does not apply
     assert not pkg.BatchOptimization(pkg.default_params(**over), max_batch=64, dtype=torch.float64, device=0, wide_qp=True).wide_qp
-    assert not pkg.BatchOptimization(pkg.default_params(**over), max_batch=64, dtype=torch.float32, device=0, wide_qp=True,
-                                     model="double").wide_qp
+    mk = lambda **kw: pkg.BatchOptimization(pkg.default_params(**over), max_batch=64, dtype=torch.float32, device=0, **kw)  # noqa: E731
+    assert not mk().wide_qp and mk(model="double").wide_qp and not mk(model="double", wide_qp=False).wide_qp   # the defaults
     assert not pkg.BatchOptimization(pkg.default_params(window_length=30, state_spacing=6, **over), max_batch=64,
                                      dtype=torch.float32, device=0, wide_qp=True).wide_qp   # run-time-spacing kernel
     # closed loop with exits: no solver failure, poles stand
