@@ -13,8 +13,10 @@
 // dense float KKT solve with pivoting (2e-2 / 2e-2 / 1e-3).
 // A double kernel keeps its own type.  (Round 4 tried double-double there for horizons beyond 1 s: it removes the
 // rounding of S but not that of W q and of the forward state recovery, which amplify by the same e^{6 t}; the result
-// was no better than plain double with its refinement pass, so it is not in the code.  Such horizons are refused at
-// creation unless asked for explicitly: include/cpmpc.h, CPMPC_CREATE_ALLOW_LONG_HORIZON.)
+// was no better than plain double with its refinement pass, so it is not in the code.  Such horizons are solved with a
+// warning, or refused with CPMPC_CREATE_STRICT_HORIZON: include/cpmpc.h.)
+// Round 5: CPMPC_CREATE_WIDE_QP extends the double part of a float kernel from the NX x NX system to the whole terminal
+// part of the QP (mpc_fused_body.inc: type Q).
 #pragma once
 #include <hip/hip_runtime.h>
 

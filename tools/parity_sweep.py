@@ -49,7 +49,7 @@ CASES = [
     ("the same, split pipeline", 16384, dict(NO_TOL, max_iterations=200), DYN_UI, 0.0, "single", "split"),
     ("N=80 sp=10 (8 intervals), 4 its", 32768, dict(NO_TOL, window_length=80, max_iterations=4), DYN_UI, 0.0, "single", "auto"),
     # where does the condensed QP stop reproducing the full-space solve?  (cpmpc_max_parity_horizon: the library refuses
-    # horizons beyond 0.8 s unless CPMPC_CREATE_ALLOW_LONG_HORIZON is given)
+    # horizons beyond 1.0 s only with CPMPC_CREATE_STRICT_HORIZON since round 5; allow_long_horizon silences the warning)
     ("N=100 sp=10 (10 intervals), 3 its", 16384, dict(NO_TOL, window_length=100, max_iterations=3), DYN_UI, 0.0, "single", "auto"),
     ("N=100 sp=10 (10 intervals), 5 its", 32768, dict(NO_TOL, window_length=100, max_iterations=5), DYN_UI, 0.0, "single", "auto"),
     ("N=100 sp=10, reference defaults: 8 its, exits on", 32768, dict(window_length=100), DYN_UI, 0.0, "single", "auto"),
