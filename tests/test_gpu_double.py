@@ -271,3 +271,11 @@ def test_double_float_handles_carry_the_qp_in_double_by_default(pkg, orc):
     assert res[None][0] >= 0.97 and res[None][1] <= 1.5e-3
     assert (e_cpu < 1e-2).mean() >= 0.97
     assert res[False][0] < 0.5
+    # a spacing without a compiled specialisation (N = 30, spacing 6: the run-time-spacing kernel) has it as well
+    over6 = dict(over, window_length=30, state_spacing=6)
+    u64, _, st64, _, _ = orc.step_batch_cold(orc.default_opt_params(**over6), DYN, 0.0, x0[:, :1024], model="double")
+    opt = pkg.BatchOptimization(pkg.default_params(**over6), max_batch=1024, dtype=torch.float32, device=0, model="double")
+    assert opt.wide_qp and opt.pipeline() == "fused"
+    o = opt.step(T(x0[:, :1024], torch.float32), DYN, 0.0)
+    err = np.abs(N_(o.u.double()) - u64).max(axis=0)
+    assert (N_(o.status) == st64).all() and (err < 1e-2).mean() >= 0.97, ((err < 1e-2).mean(), np.median(err))
