@@ -279,3 +279,28 @@ def test_double_float_handles_carry_the_qp_in_double_by_default(pkg, orc):
     o = opt.step(T(x0[:, :1024], torch.float32), DYN, 0.0)
     err = np.abs(N_(o.u.double()) - u64).max(axis=0)
     assert (N_(o.status) == st64).all() and (err < 1e-2).mean() >= 0.97, ((err < 1e-2).mean(), np.median(err))
+
+
+def test_double_float_closed_loop_balances_without_solver_failures(pkg, orc):
+    """The 6-state model in single precision, closed loop (pkg.ClosedLoop, the float handle's default: QP in double): 2 048
+    controllers balance both poles for 3 s from within 0.05 rad of upright with the soft terminal weights of
+    test_double_closed_loop_and_warm_start -- never QP_INDEFINITE / MAX_LAMBDA / NON_FINITE (optimization_test.cc:44-46 for
+    this model), poles upright within 1e-2 rad and the cart at rest at the end."""
+    rng = np.random.default_rng(19)
+    B = 2048
+    x0 = near_upright(rng, B, 0.05)
+    x0[0] *= 0.2
+    x0[3:] *= 0.2
+    over = dict(OVER, max_iterations=10, **SOFT)
+    loop = pkg.ClosedLoop(pkg.default_params(**over), B, dtype=torch.float32, device=0, model="double")
+    assert loop.opts[0].wide_qp
+    loop.set_state(T(x0, torch.float32))
+    bad = torch.zeros((), dtype=torch.int64, device=DEV)
+    fails = torch.tensor([orc.TERM_QP_INDEFINITE, orc.TERM_MAX_LAMBDA, orc.TERM_NON_FINITE], dtype=torch.int32, device=DEV)
+    for _ in range(300):
+        loop.tick(DYN, 0.0)
+        bad += torch.isin(loop.status(), fails).sum()
+    s = N_(loop.state().double())
+    assert int(bad.item()) == 0
+    assert np.abs(s[1] - np.pi / 2).max() < 1e-2 and np.abs(s[2] - np.pi / 2).max() < 1e-2, (np.abs(s[1] - np.pi / 2).max(), np.abs(s[2] - np.pi / 2).max())
+    assert np.abs(s[3:]).max() < 5e-2
