@@ -25,6 +25,8 @@ ap.add_argument("--start", choices=["near-upright", "anywhere"], default="anywhe
 ap.add_argument("--fo-tol", type=float, default=None, help="absolute_first_derivative_tol (reference default 1e-6)")
 ap.add_argument("--pipeline", choices=["auto", "split", "fused"], default="auto")
 ap.add_argument("--compaction", default=None, help="first:next iterations of the staged fused pipeline (cpmpc_set_compaction); default: the library's")
+ap.add_argument("--model", choices=["single", "double"], default="single", help="double: the 6-state model, near-upright starts "
+                "(within 0.05 rad), soft terminal weights (the configuration that balances robustly, tests/test_gpu_double.py)")
 ap.add_argument("--out", default=None)
 args = ap.parse_args()
 dt = torch.float32 if args.dtype == "f32" else torch.float64
@@ -34,10 +36,16 @@ if args.start == "near-upright":
     x0 = np.stack([rng.uniform(-0.3, 0.3, B), np.pi / 2 + rng.uniform(-0.4, 0.4, B), rng.uniform(-0.5, 0.5, B), rng.uniform(-1, 1, B)])
 else:   # the benchmark's distribution: any pole angle (swing-up for most)
     x0 = np.stack([rng.uniform(-0.6, 0.6, B), rng.uniform(-np.pi, np.pi, B), rng.uniform(-1, 1, B), rng.uniform(-3, 3, B)])
-sim = pkg.BatchSimulator(B, dtype=dt, device=0)
-sim.set_state(torch.tensor(x0, dtype=dt, device="cuda:0"))
 over = {} if args.fo_tol is None else {"absolute_first_derivative_tol": args.fo_tol}
-opt = pkg.BatchOptimization(pkg.default_params(**over), max_batch=B, dtype=dt, device=0)
+if args.model == "double":
+    DYN_UI = [1.0, 0.1, 0.1, 0.25, 0.2, 9.81]
+    x0 = np.stack([0.2 * rng.uniform(-0.3, 0.3, B), np.pi / 2 + rng.uniform(-0.05, 0.05, B), np.pi / 2 + rng.uniform(-0.05, 0.05, B),
+                   0.2 * rng.uniform(-0.3, 0.3, B), 0.2 * rng.uniform(-0.5, 0.5, B), 0.2 * rng.uniform(-0.5, 0.5, B)])
+    over.update(u_guess_sinusoid_amplitude=0.0, max_iterations=10, state_spacing=5, th_final_cost_weight=200.0,
+                th_dot_final_cost_weight=20.0, b_x_dot_final_cost_weight=20.0)
+sim = pkg.BatchSimulator(B, dtype=dt, device=0, model=args.model)
+sim.set_state(torch.tensor(x0, dtype=dt, device="cuda:0"))
+opt = pkg.BatchOptimization(pkg.default_params(**over), max_batch=B, dtype=dt, device=0, model=args.model)
 opt.set_pipeline(args.pipeline)
 if args.compaction:
     opt.set_compaction(*(int(v) for v in args.compaction.split(":")))
@@ -66,7 +74,9 @@ torch.cuda.synchronize()
 wall = time.perf_counter() - t0
 s = sim.get_state().double().cpu().numpy()
 err = np.abs(s[1] - np.pi / 2)
-res = {"dtype": args.dtype, "pipeline": opt.pipeline(), "absolute_first_derivative_tol": args.fo_tol if args.fo_tol is not None else 1e-6, "batch": B, "ticks": args.ticks, "start": args.start, "wall_s": wall, "ms_per_tick": wall / args.ticks * 1e3,
+if args.model == "double":
+    err = np.maximum(err, np.abs(s[2] - np.pi / 2))
+res = {"dtype": args.dtype, "model": args.model, "wide_qp": opt.wide_qp, "pipeline": opt.pipeline(), "absolute_first_derivative_tol": args.fo_tol if args.fo_tol is not None else 1e-6, "batch": B, "ticks": args.ticks, "start": args.start, "wall_s": wall, "ms_per_tick": wall / args.ticks * 1e3,
        "controller_ticks_per_s": B * args.ticks / wall, "status_histogram_total": hist_total,
        "ticks_with_QP_INDEFINITE_MAX_LAMBDA_or_NON_FINITE": len(bad_ticks), "first_such_ticks": bad_ticks[:20],
        "final": {"upright_within_1e-3": float((err < 1e-3).mean()), "upright_within_1e-4": float((err < 1e-4).mean()),
