@@ -178,6 +178,14 @@ def test_long_horizons_are_accepted_and_refused_only_when_asked(lib, pkg, capfd)
         lib.cpmpc_destroy(h)
     assert lib.cpmpc_create_ex(C.byref(info(struct_size=12)), C.byref(h)) == pkg.capi.ERR_INVALID_ARG
     assert lib.cpmpc_create_ex(C.byref(info(flags=0x80)), C.byref(h)) == pkg.capi.ERR_INVALID_ARG
+    # the pairs of flags that force one thing on and off exclude each other; each alone is accepted
+    for pair in (pkg.capi.CREATE_REFINE_QP | pkg.capi.CREATE_NO_REFINE_QP, pkg.capi.CREATE_WIDE_QP | pkg.capi.CREATE_NO_WIDE_QP):
+        assert lib.cpmpc_create_ex(C.byref(info(flags=pair)), C.byref(h)) == pkg.capi.ERR_INVALID_ARG
+    for one in (pkg.capi.CREATE_REFINE_QP, pkg.capi.CREATE_NO_REFINE_QP, pkg.capi.CREATE_WIDE_QP, pkg.capi.CREATE_NO_WIDE_QP):
+        rc = lib.cpmpc_create_ex(C.byref(info(flags=one)), C.byref(h))
+        assert rc in past, one
+        if h.value:
+            lib.cpmpc_destroy(h)
     o = pkg.capi.default_solver_opts()
     assert lib.cpmpc_create_ex(C.byref(info(flags=1, opts=C.pointer(o), opts_size=C.sizeof(o) + 8)),
                                C.byref(h)) == pkg.capi.ERR_INVALID_ARG
