@@ -11,7 +11,10 @@ cd /tmp
 O="$R/gpurun_out/prof_$TAG"
 mkdir -p "$O"
 COMMON=(--no-cpu-baseline --no-variants --no-fp64 --no-clock --preheat-seconds 0 "${EXTRA[@]}")
-rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -- python3 "$R/bench.py" --steps 10 --warmup 2 "${COMMON[@]}" > "$O/kt.log" 2>&1
+# the kernel trace runs the driver's command line (20 steps after 5 warm-up steps, behind bench.py's 2 s pre-heat: the trace then
+# averages ~1 000 launches of each kernel on a device in the state the bench line is measured in); the counter passes below
+# serialise kernels and take 3 steps without the pre-heat
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -- python3 "$R/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-variants --no-fp64 --no-clock "${EXTRA[@]}" > "$O/kt.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/fetch" -- python3 "$R/bench.py" --steps 3 --warmup 1 "${COMMON[@]}" > "$O/fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/write" -- python3 "$R/bench.py" --steps 3 --warmup 1 "${COMMON[@]}" > "$O/write.log" 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d "$O/sq" -- python3 "$R/bench.py" --steps 3 --warmup 1 "${COMMON[@]}" > "$O/sq.log" 2>&1
