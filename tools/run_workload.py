@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--pipeline", choices=["auto", "split", "fused"], default="auto")
     ap.add_argument("--settle", type=int, default=0, help="closed_loop: untimed ticks first, from the benchmark's state "
                     "distribution, so that the timed ones are settled ticks (tools/settled_trace.py reads the trace)")
+    ap.add_argument("--preheat", type=float, default=0.0, help="seconds of untimed steps first (the kernel-trace pass of "
+                    "prof_workload.sh: rocprofv3's average is then that of a warm process, like bench.py's line)")
     a = ap.parse_args()
     dt = torch.float32 if a.dtype == "f32" else torch.float64
     rng = np.random.default_rng(7)
@@ -83,6 +85,11 @@ def main():
         if a.settle:
             torch.cuda.synchronize()   # a controller acts on u every tick: the stage plan then follows the tick before
     torch.cuda.synchronize()
+    t_pre = time.perf_counter()
+    while a.preheat > 0.0 and time.perf_counter() - t_pre < a.preheat:
+        for _ in range(16):
+            step()
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
