@@ -164,7 +164,7 @@ static void launch_fused(const SolverArgs<R, M>& a, int L, int SP, int max_iters
     const size_t lds = fused_dyn_lds_bytes<R, M>(SP);
 #define CPMPC_FUSED_DYN(LV)                                                                                         \
   if (L == LV) {                                                                                                    \
-    if constexpr (sizeof(R) == 8 || M::NX > 4) { /* double: REFINE_QP; float, 6-state model: WIDE_QP */            \
+    { /* double: REFINE_QP; float: WIDE_QP */                                                                       \
       if (refine) {                                                                                                 \
         hipLaunchKernelGGL((fused_sqp_dyn_kernel<R, M, LV, false, true>), grid, dim3(64), lds, stream, a, max_iters); \
         return;                                                                                                     \

@@ -206,9 +206,8 @@ int cpmpc_refines_qp(const cpmpc_solver* s); /* 1: this handle's kernels refine 
  *                                for 0 - 5 % (51.0 -> 50.8 M near upright, 50.9 -> 48.3 M from within 0.5 rad).
  * DEFAULT (neither flag): ON for the 6-state model -- without it four of five float solves of that model are off by more
  * than 0.01 N after five iterations -- and OFF for the 4-state one (the reference's model: speed first, the bar of this
- * path is met by CPMPC_F64 handles).  The fused pipeline only; for the 4-state model the compiled state spacings only
- * (cpmpc_supported_state_spacing() == 2: hipcc 7.2 cannot compile the run-time-spacing kernel with it), for the 6-state
- * model every spacing the fused pipeline serves.  cpmpc_wide_qp() tells what a handle does. */
+ * path is met by CPMPC_F64 handles).  The fused pipeline only (every spacing it serves; the split pipeline keeps the
+ * round-4 arithmetic).  cpmpc_wide_qp() tells what a handle does. */
 int cpmpc_wide_qp(const cpmpc_solver* s);
 /* seconds: the longest horizon held to 1e-5 of the CPU check on every problem (1.0) */
 double cpmpc_max_parity_horizon(void);
