@@ -27,7 +27,9 @@ The same line also carries the record of the parity dtype (`fp64`: the reference
 only, optimization/single_pendulum_dynamics.hpp:185): the same workload at the same batch in fp64,
 timed the same way, with its own roofline and its control sequences compared with the CPU oracle.
 
-Prints ONE JSON line on rank 0 (see the driver contract in the task description).
+Rank 0 prints ONE compact JSON line (< 1 900 bytes: the driver contract's keys, `roofline`, `cpu_baseline` and the
+summary scalars of the parity dtype -- `compact_line`) and writes everything else the run measured (variants, notes,
+per-rank tables) to `bench_detail.json` next to this script (`--detail PATH`; copied to gpurun_out/ when that exists).
 """
 import argparse
 import gc
@@ -603,11 +605,12 @@ def variants(torch, pkg, args, tdt, dev, local_rank, x0, B):
         res["shards_on_streams"] = split_streams_variant(torch, pkg, args, dev, local_rank, B)
     except Exception as exc:  # noqa: BLE001
         res["shards_on_streams"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
-    try:
-        quiesce(torch)
-        res["plain_sqp"] = plain_sqp_variant()
-    except Exception as exc:  # noqa: BLE001
-        res["plain_sqp"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    if args.plain_sqp:   # four 1 000-tick soaks in child processes (~15 s): only when asked for, never in the driver's command
+        try:
+            quiesce(torch)
+            res["plain_sqp"] = plain_sqp_variant()
+        except Exception as exc:  # noqa: BLE001
+            res["plain_sqp"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     try:
         res["single_controller_facade"] = single_controller_latency(pkg)
     except Exception as exc:  # noqa: BLE001
@@ -1277,7 +1280,97 @@ def run_rank(args):
     import ctypes
     sys.stdout.flush()
     ctypes.CDLL(None).fflush(None)
-    print(json.dumps(line), flush=True)
+    detail_path = write_detail(line, args.detail)
+    print(json.dumps(compact_line(line, detail_path), separators=(",", ":")), flush=True)
+
+
+def _sig(v, digits=6):
+    """A float at `digits` significant digits (the compact line is read by people and by a 2 000-character tail)."""
+    if isinstance(v, bool) or not isinstance(v, float):
+        return v
+    if v != v or v in (float("inf"), float("-inf")):
+        return None
+    return float("%.*g" % (digits, v))
+
+
+def _dig(d, *path):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d
+
+
+COMPACT_LIMIT = 1900   # bytes; the driver keeps a 2 000-character tail of stdout and parses its last line
+
+
+def compact_line(line, detail_path=None):
+    """The ONE line stdout carries: the driver contract's keys, `roofline` and `cpu_baseline` without
+    their notes, and the summary scalars of the parity dtype and of the float kernels' parity option.  Everything else
+    the run measured (variants, notes, per-rank tables) is the detail record `write_detail` leaves next to this script.
+    Never longer than COMPACT_LIMIT bytes: optional keys are dropped from the end until it fits."""
+    c = {k: _sig(line.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                        "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    cfg = line.get("config") or {}
+    c["config"] = {k: cfg.get(k) for k in ("workload", "batch_per_gpu", "global_batch", "horizon", "sqp_iterations",
+                                           "pipeline", "parallelism")}
+    r = line.get("roofline") or {}
+    c["roofline"] = {k: _sig(r.get(k)) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
+                                                 "avg_launch_ms", "launches")}
+    b = line.get("cpu_baseline")
+    if isinstance(b, dict):
+        c["cpu_baseline"] = {k: _sig(b.get(k)) for k in ("value", "unit", "cores", "kind", "one_core_value")}
+        c["cpu_baseline"]["sample"] = (b.get("sample") or "")[:150]
+    # the parity dtype (fp64: the reference's own arithmetic) and what the float kernels' accuracy option costs / buys
+    opt = [("fp64_value", _dig(line, "fp64", "value")),
+           ("fp64_frac", _dig(line, "fp64", "roofline", "frac")),
+           ("parity_f64_lanes_over_1e-5", _dig(line, "parity_f64", "lanes_over_1e-5")),
+           ("parity_f64_lanes", _dig(line, "parity_f64", "lanes")),
+           ("wide_qp_f32_value", _dig(line, "variants", "wide_qp_f32", "wide_qp", "re-plans/s")),
+           ("wide_qp_f32_within_1e-2", _dig(line, "variants", "wide_qp_f32", "wide_qp", "parity_vs_cpu_check", "fraction_within_1e-2")),
+           ("f32_within_1e-2", _dig(line, "variants", "wide_qp_f32", "default", "parity_vs_cpu_check", "fraction_within_1e-2")),
+           ("config5_f64_value", _dig(line, "variants", "double_pendulum", "within_0.5rad", "f64", "re-plans/s")),
+           ("config5_f64_frac", _dig(line, "variants", "double_pendulum", "within_0.5rad", "f64", "roofline", "frac")),
+           ("config5_f32_value", _dig(line, "variants", "double_pendulum", "within_0.5rad", "f32", "re-plans/s")),
+           ("gather_ms", _dig(line, "distributed", "gather_ms")),
+           ("backend", _dig(line, "distributed", "backend")),
+           ("rank_ms_per_step_min", _dig(line, "distributed", "per_rank", "ms_per_step_own_min")),
+           ("rank_ms_per_step_max", _dig(line, "distributed", "per_rank", "ms_per_step_own_max")),
+           ("as_rank", [line["as_rank"]["rank"], line["as_rank"]["of"]] if isinstance(line.get("as_rank"), dict) else None),
+           ("detail", os.path.basename(detail_path) if detail_path else None)]
+    for k, v in opt:
+        if v is not None:
+            c[k] = _sig(v)
+    order = [k for k, _ in opt]
+    while len(json.dumps(c, separators=(",", ":"))) >= COMPACT_LIMIT and order:
+        c.pop(order.pop(), None)
+    if len(json.dumps(c, separators=(",", ":"))) >= COMPACT_LIMIT:   # a workload string somebody made long: cut it, keep the numbers
+        c["config"]["workload"] = (c["config"].get("workload") or "")[:200]
+        if isinstance(c.get("cpu_baseline"), dict):
+            c["cpu_baseline"]["sample"] = c["cpu_baseline"]["sample"][:60]
+    return c
+
+
+def write_detail(line, path):
+    """The full record of the run (what rounds 1-5 printed as one 25 KB line), written by rank 0 only, atomically; also
+    copied to gpurun_out/ when that directory exists (the only thing a gpurun call brings home).  Returns the path, or
+    None when nothing could be written -- the compact line prints regardless."""
+    if not path:
+        return None
+    text = json.dumps(line, indent=1)
+    done = None
+    for p in (path, os.path.join(ROOT, "gpurun_out", os.path.basename(path))):
+        if p != path and not os.path.isdir(os.path.dirname(p)):
+            continue
+        try:
+            tmp = "%s.tmp.%d" % (p, os.getpid())
+            with open(tmp, "w") as fh:
+                fh.write(text + "\n")
+            os.replace(tmp, p)
+            done = done or p
+        except OSError as exc:
+            sys.stderr.write("bench.py: could not write %s: %s\n" % (p, exc))
+    return done
 
 
 def parse_args(argv=None):
@@ -1295,6 +1388,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-fp64", action="store_true", help="skip the fp64 record")
     ap.add_argument("--no-variants", action="store_true", help="skip the secondary measurements (SURVEY 8d)")
     ap.add_argument("--no-clock", action="store_true", help="skip the shader-clock / issue-ceiling leg")
+    ap.add_argument("--plain-sqp", action="store_true", help="also run tools/plain_sqp.py's soaks (the price of the solver "
+                    "specification's three additions, DESIGN.md section 4) into the detail record")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"), help="where rank 0 writes the full record "
+                    "(variants, notes, per-rank tables); stdout carries only the compact line")
     ap.add_argument("--pipeline", choices=["auto", "split", "fused"], default="auto")
     ap.add_argument("--as-rank", type=int, default=None, help="with --of W: solve rank R's shard of the W-GPU global "
                     "batch alone on this GPU (no process group)")

@@ -34,6 +34,80 @@ def test_last_json_line():
     assert bench.last_json_line("{not json}\n") is None
 
 
+def _full_record(world=1):
+    """A stand-in for the record run_rank() assembles (every key the compact line reads, plus bulk that must NOT travel)."""
+    line = {"metric": "MPC re-plans/sec (whole node), N=40 horizon, 5 SQP iters, batch 256k", "value": 121234567.891 * world,
+            "unit": "re-plans/s", "n_gpus": world, "steps": 20, "warmup": 5, "ms_per_step": 2.162345678, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "preheated": True,
+            "config": {"workload": "BASELINE configs[3]: batch=262144 per GPU (2097152 in total), N=40, state_spacing=10, f32, "
+                                   "cold start, 5 SQP iterations (exits disabled), u+predicted+status written, u gathered to "
+                                   "rank 0 (RCCL)", "batch_per_gpu": 262144, "global_batch": 262144 * world, "horizon": 40,
+                       "sqp_iterations": 5, "pipeline": "fused", "parallelism": "dp%d" % world},
+            "roofline": {"bound": "valu", "kernel": "fused_sqp_kernel", "achieved": 74.212345, "peak": 157.3, "unit": "TFLOP/s",
+                         "frac": 0.47181234, "traffic": 221098765.4321, "avg_launch_ms": 1.97923456, "launches": 20,
+                         "note": "n" * 600, "hbm": {"x": 1}, "kernels_ms_per_step": {"a": 1.0}, "issue": {"note": "i" * 500}},
+            "cpu_baseline": {"value": 63123.456789, "unit": "re-plans/s", "cores": 16, "kind": "port",
+                             "one_core_value": 4061.23456, "parallel_efficiency": 0.97, "host": {"os_cpu_count": 256},
+                             "sample": "first 262144 problems of rank 0's batch, same N=40/5-iteration cold-start workload, "
+                                       "fp64, oracle/cpmpc_oracle.c with OpenMP (16 threads), 4.1 s " + "s" * 300},
+            "fp64": {"value": 50234567.89, "roofline": {"frac": 0.38123456, "note": "x" * 500}},
+            "parity_f64": {"lanes_over_1e-5": 0, "lanes": 262144, "arbiter": {"note": "a" * 300}},
+            "variants": {"wide_qp_f32": {"wide_qp": {"re-plans/s": 117912345.6, "parity_vs_cpu_check": {"fraction_within_1e-2": 0.99426}},
+                                         "default": {"re-plans/s": 122.0e6, "parity_vs_cpu_check": {"fraction_within_1e-2": 0.9366}}},
+                         "double_pendulum": {"within_0.5rad": {"f64": {"re-plans/s": 23.3e6, "roofline": {"frac": 0.33}},
+                                                               "f32": {"re-plans/s": 50.1e6}}},
+                         "closed_loop_settled": {"note": "c" * 4000}}}
+    if world > 1:
+        line["distributed"] = {"backend": "nccl", "gather_ms": 0.31234567,
+                               "per_rank": {"ms_per_step_own": [2.1] * world, "ms_per_step_own_min": 2.1012345,
+                                            "ms_per_step_own_max": 2.1698765, "sqp_kernel_ms_per_launch": [1.98] * world,
+                                            "gather_ms": [0.3] * world, "note": "p" * 300}}
+    return line
+
+
+@pytest.mark.parametrize("world", [1, 8])
+def test_final_line_is_short(world, tmp_path):
+    """the line the driver parses is < 1 900 bytes (it keeps a 2 000-character tail of stdout) and still
+    carries the contract's keys, `roofline`, `cpu_baseline` and the summary scalars; the bulk goes to the detail file."""
+    full = _full_record(world)
+    assert len(json.dumps(full)) > 5000
+    detail = bench.write_detail(full, str(tmp_path / "bench_detail.json"))
+    assert detail and json.load(open(detail)) == json.loads(json.dumps(full))
+    text = json.dumps(bench.compact_line(full, detail), separators=(",", ":"))
+    assert len(text) < 1900 and "\n" not in text
+    c = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in c, k
+    assert c["n_gpus"] == world and abs(c["value"] / full["value"] - 1) < 1e-5
+    assert set(c["roofline"]) == {"bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches"}
+    assert abs(c["roofline"]["frac"] - c["roofline"]["achieved"] / c["roofline"]["peak"]) < 1e-3
+    assert {"value", "unit", "cores", "kind", "sample", "one_core_value"} <= set(c["cpu_baseline"])
+    assert c["config"]["workload"].startswith("BASELINE configs[") and "model" not in c["config"]
+    assert c["fp64_value"] == pytest.approx(50234567.89, rel=1e-5) and c["fp64_frac"] == pytest.approx(0.381235, rel=1e-5)
+    assert c["parity_f64_lanes_over_1e-5"] == 0 and c["wide_qp_f32_value"] == pytest.approx(117912345.6, rel=1e-5)
+    assert c["wide_qp_f32_within_1e-2"] == pytest.approx(0.99426) and c["detail"] == "bench_detail.json"
+    if world > 1:
+        assert c["backend"] == "nccl" and c["rank_ms_per_step_max"] == pytest.approx(2.16988, rel=1e-5)
+    assert "variants" not in c and "note" not in c["roofline"] and "distributed" not in c
+
+
+def test_final_line_stays_short_when_strings_grow():
+    """Optional keys are shed from the end and over-long strings cut before the line may pass the limit."""
+    full = _full_record(8)
+    full["config"]["workload"] = "w" * 3000
+    text = json.dumps(bench.compact_line(full, "bench_detail.json"), separators=(",", ":"))
+    assert len(text) < 1900
+    c = json.loads(text)
+    assert "roofline" in c and "cpu_baseline" in c and c["value"] > 0
+
+
+def test_the_driver_command_does_not_run_the_soaks():
+    """The 1 000-tick plain-SQP soaks (four child processes) run only behind --plain-sqp."""
+    assert bench.parse_args(["--gpus", "1", "--steps", "20", "--warmup", "5"]).plain_sqp is False
+    assert bench.parse_args(["--plain-sqp"]).plain_sqp is True
+
+
 def test_global_batch_is_one_seeded_batch():
     full = bench.synth_states(bench.SEED, 64)
     assert np.array_equal(bench.synth_states(bench.SEED, 64, 16, 32), full[:, 16:32])

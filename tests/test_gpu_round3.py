@@ -26,10 +26,19 @@ def T(a, dtype=torch.float64):
 def _bench(args, env_extra=None, timeout=900):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env.update(env_extra or {})
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
-                       timeout=timeout)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    return json.loads(r.stdout.strip().splitlines()[-1])
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        detail = os.path.join(tmp, "bench_detail.json")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args + ["--detail", detail], env=env,
+                           capture_output=True, text=True, timeout=timeout)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        last = r.stdout.strip().splitlines()[-1]
+        compact = json.loads(last)          # what the driver parses: one short line ...
+        assert len(last) < 1900 and "roofline" in compact and compact["detail"] == "bench_detail.json"
+        full = json.load(open(detail))      # ... and the full record beside it
+    for k in ("value", "n_gpus", "steps", "ms_per_step"):
+        assert compact[k] == pytest.approx(full[k], rel=1e-5)
+    return full
 
 
 # ------------------------------------------------------------------------------------------------

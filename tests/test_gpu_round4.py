@@ -532,16 +532,20 @@ def test_sharded_cpp_facade_hand_over_and_per_problem_inputs():
     assert "two host threads x 6 chunked steps" in r.stdout   # the worker pool under two concurrent callers
 
 
-def test_bench_with_four_ranks_on_the_one_gpu():
+def test_bench_with_four_ranks_on_the_one_gpu(tmp_path):
     """`bench.py --gpus 4` the way the driver starts it, the four ranks sharing the one device (gloo gather; the box
     allows six GPU processes at once, so eight ranks on one GPU are not possible here -- the eight-rank launcher path is
     covered on the CPU by tests/test_bench_launcher.py::test_launcher_spawns_world_of_eight)."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env["CPMPC_BENCH_SHARE_DEVICE"] = "1"
+    detail = str(tmp_path / "bench_detail.json")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--batch", "4096", "--steps", "3",
-                        "--warmup", "1"], env=env, capture_output=True, text=True, timeout=900)
+                        "--warmup", "1", "--detail", detail], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    line = json.loads(r.stdout.strip().splitlines()[-1])
+    last = r.stdout.strip().splitlines()[-1]
+    compact = json.loads(last)
+    assert len(last) < 1900 and compact["n_gpus"] == 4 and compact["rank_ms_per_step_max"] >= compact["rank_ms_per_step_min"] > 0
+    line = json.load(open(detail))
     d = line["distributed"]
     assert line["n_gpus"] == 4 and d["world_size_seen"] == 4 and d["spawned_by_bench"]
     assert line["gathered"]["shape"] == [40, 4 * 4096] and line["gathered"]["own_block_intact"]

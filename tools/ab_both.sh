@@ -5,8 +5,8 @@ cd "$(dirname "$0")/.."
 for rep in 1 2; do
 for v in ${VARIANTS:-default}; do
   if [ "$v" = default ]; then unset CPMPC_LIB; else export CPMPC_LIB=$PWD/tools/_build/lib_$v/libcpmpc.so; fi
-  python bench.py --steps 60 --no-variants --no-cpu-baseline --no-clock 2>/dev/null | python -c "
+  python bench.py --steps 60 --no-variants --no-cpu-baseline --no-clock --detail /tmp/ab_detail.json > /dev/null 2>&1; python -c "
 import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['roofline']['kernels_ms_per_step']; k6=d['fp64']['roofline']['kernels_ms_per_step']
+d=json.load(open('/tmp/ab_detail.json')); k=d['roofline']['kernels_ms_per_step']; k6=d['fp64']['roofline']['kernels_ms_per_step']
 print('$v', 'f32', round(d['value']/1e6,2), k['fused_sqp_kernel'], 'prep/fin', k['prepare_kernel'], k['finalize_kernel'], 'f64', round(d['fp64']['value']/1e6,2), k6['fused_sqp_kernel'], 'prep/fin', k6['prepare_kernel'], k6['finalize_kernel'])"
 done; done

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 for rep in 1 2; do
 for v in ${VARIANTS:-default notable norotate nomerge r2math}; do
   if [ "$v" = default ]; then unset CPMPC_LIB; else export CPMPC_LIB=$PWD/tools/_build/lib_$v/libcpmpc.so; fi
-  python bench.py --dtype f64 --steps 60 --no-variants --no-cpu-baseline --no-clock --no-fp64 2>/dev/null | python -c "
+  python bench.py --dtype f64 --steps 60 --no-variants --no-cpu-baseline --no-clock --no-fp64 --detail /tmp/ab_detail.json > /dev/null 2>&1; python -c "
 import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', round(d['value']/1e6,2), d['roofline']['kernels_ms_per_step'])"
+d=json.load(open('/tmp/ab_detail.json')); print('$v', round(d['value']/1e6,2), d['roofline']['kernels_ms_per_step'])"
 done; done
