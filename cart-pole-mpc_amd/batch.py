@@ -421,11 +421,27 @@ class ClosedLoop:
             # one range: the caller's stream, like BatchOptimization alone; several: a stream each
             self.streams.append(torch.cuda.Stream(device=self.device) if ranges > 1 else None)
         self.ticks = 0
+        self._inputs_dirty = len(self.sims) > 1   # the plants' initial states were written on the caller's stream
 
     def set_state(self, state):
-        """state: [nx, B] tensor, columns in the caller's order."""
+        """state: [nx, B] tensor, columns in the caller's order.  May be called at any tick (a disturbance, a reset): with
+        several ranges the copy is made ON each range's stream after that stream has waited for the caller's, so neither the
+        range's solver / plant can read the new state before it has landed nor the caller's allocator hand the old one out
+        while the range's plant is still reading it."""
+        cur = torch.cuda.current_stream(self.device)
         for i, s in enumerate(self.sims):
-            s.set_state(state[:, self.bounds[i]:self.bounds[i + 1]].contiguous())
+            part = state[:, self.bounds[i]:self.bounds[i + 1]]
+            st = self.streams[i]
+            if st is None:
+                s.set_state(part.contiguous())
+                continue
+            st.wait_stream(cur)                      # whatever produced `state` on the caller's stream comes first
+            old = s.state
+            with torch.cuda.stream(st):
+                s.set_state(part)                    # the clone is queued on, and belongs to the pool of, the range's stream
+            part.record_stream(st)                   # `state` is read there: its memory is not reused before that copy
+            old.record_stream(st)                    # the plant of the last tick may still be reading the replaced tensor
+        self._inputs_dirty = len(self.sims) > 1
 
     def _on(self, i):
         st = self.streams[i]
@@ -433,13 +449,26 @@ class ClosedLoop:
 
     def tick(self, dyn, set_point=0.0, dt=0.01, want_stats=True):
         """One MPC tick of every controller (queued, not waited for)."""
-        if self.ticks == 0 and len(self.sims) > 1:
+        if isinstance(dyn, torch.Tensor):
+            raise TypeError("ClosedLoop.tick: dyn is the plant's parameter set too (cpmpc_sim_step_batch takes shared host "
+                            "parameters): pass the %d numbers, not a tensor" % self.sims[0].np)
+        tensors = [t for t in (set_point,) if isinstance(t, torch.Tensor)]
+        if len(self.sims) > 1 and (self._inputs_dirty or tensors):
+            # whatever prepared the states -- or this tick's per-problem parameters / set-points -- on the caller's stream
+            # comes first.  Shared (host) parameters and no set_state since the last tick: no wait, the ranges run free.
             cur = torch.cuda.current_stream(self.device)
-            for st in self.streams:   # whatever prepared the states on the caller's stream comes first
+            for st in self.streams:
                 st.wait_stream(cur)
+                for t in tensors:
+                    t.record_stream(st)
+            self._inputs_dirty = False
+        one = len(self.sims) == 1
         for i, (s, o, out) in enumerate(zip(self.sims, self.opts, self.outs)):
+            lo, hi = self.bounds[i], self.bounds[i + 1]
             with self._on(i):
-                r = o.step(s.get_state(), dyn, set_point, want_predicted=False, want_stats=want_stats, out=out)
+                # per-problem set-points [B]: this range's columns (copied on the range's stream)
+                sp = set_point if one or not isinstance(set_point, torch.Tensor) else set_point[lo:hi].contiguous()
+                r = o.step(s.get_state(), dyn, sp, want_predicted=False, want_stats=want_stats, out=out)
                 s.step(dyn, dt, r.u[0].contiguous())
         self.ticks += 1
 

@@ -197,6 +197,49 @@ def test_closed_loop_as_column_ranges_is_bitwise_the_single_range(pkg, dtype):
     assert one.iterations().float().mean().item() > 1.0   # still in the transient: the ranges were not trivially idle
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_set_state_and_new_set_points_mid_run_with_column_ranges(pkg, dtype):
+    """ClosedLoop.set_state() after the first tick (a disturbance, a reset) and a per-problem set-point tensor
+    rewritten between ticks -- both prepared on the CALLER's stream, by a long chain of small kernels so that a range's
+    stream which did not wait would read them too early -- give with three ranges bit for bit what one range gives."""
+    rng = np.random.default_rng(21)
+    B = 4099
+    xs = np.stack([rng.uniform(-0.3, 0.3, B), np.pi / 2 + rng.uniform(-0.4, 0.4, B), rng.uniform(-0.5, 0.5, B), rng.uniform(-1, 1, B)])
+    loops = [pkg.ClosedLoop(pkg.default_params(), B, dtype=dtype, device=0, ranges=n) for n in (1, 3)]
+    x0 = T(xs, dtype)
+    sp = torch.zeros(B, dtype=dtype, device=x0.device)
+    for loop in loops:
+        loop.set_state(x0)
+    for k in range(24):
+        if k in (7, 15):
+            # the disturbance: built by 200 dependent kernels on the caller's stream, handed over without a synchronize;
+            # its source tensor is dropped at once (the allocator may reuse it as soon as the streams it was recorded on allow)
+            for loop in loops:
+                kick = loop.state().clone()
+                for _ in range(200):
+                    kick[3] += 0.002
+                kick[1] -= 0.05
+                loop.set_state(kick)
+                del kick
+        if k >= 10:
+            for _ in range(100):
+                sp += 0.0002 * (1 if k % 2 else -1)
+            sp_k = sp + 0.01 * torch.sin(torch.arange(B, dtype=dtype, device=sp.device))
+        else:
+            sp_k = 0.0
+        for loop in loops:
+            loop.tick(DYN_UI, sp_k)
+        if k in (7, 8, 15, 16, 23):
+            one, three = loops
+            assert torch.equal(one.state(), three.state()), k
+            assert torch.equal(one.controls(), three.controls()), k
+            assert torch.equal(one.iterations(), three.iterations()) and torch.equal(one.status(), three.status()), k
+    with pytest.raises(TypeError):
+        loops[1].tick(torch.zeros((9, B), dtype=dtype, device=x0.device), 0.0)
+    for loop in loops:
+        loop.close()
+
+
 def test_plain_sqp_tool_reports_both_phases_in_both_dtypes():
     """tools/plain_sqp.py (bench.py variants.plain_sqp runs it in child processes) at unit-test size: the specification as
     shipped against the iteration without the full-step rule and the exit floor (the -DCPMPC_SKIP_MERIT=0 library is the
