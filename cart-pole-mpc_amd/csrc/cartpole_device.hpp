@@ -584,6 +584,7 @@ template <typename R>
 struct TrigBase {
   R th0, s0, c0;
   bool valid = false;  // (th0, s0, c0) hold the previous step's stage-1 pair: this step's stage 1 may rotate from it
+  __device__ __forceinline__ void invalidate() { valid = false; }  // the next stage 1 evaluates in full (re-anchors the chain)
 };
 // The far branch of a rotation (|d| > 1 rad, or a NaN) is taken per LANE, never per wave: a problem's arithmetic must
 // not depend on what its neighbours in the wave do (batch-position independence: staged, sharded and stand-alone solves
@@ -604,14 +605,14 @@ __device__ __forceinline__ void sincos_from_base(const TrigBase<R>& tb, const R 
 #ifndef CPMPC_F64_TRIG_CHAIN
 #define CPMPC_F64_TRIG_CHAIN 0
 #endif
-template <typename R, int STAGE>
+template <typename R, int STAGE, int CHAIN = CPMPC_F64_TRIG_CHAIN>
 __device__ __forceinline__ void stage_sincos(TrigBase<R>& tb, const R th, R& s, R& c) {
   if constexpr (Math<R>::kIncrementalTrig) {
     if constexpr (STAGE == 1) {
       // consecutive steps of one rollout: this step's angle is within h |w| of the previous step's, so stage 1 rotates
       // from that pair too (one more rotation per step: the chain's error grows like the square root of its length,
       // ~1.5 ulp over the ten steps of an interval); a wrapped angle jumps by 2 pi and takes the far branch
-      if (CPMPC_F64_TRIG_CHAIN && tb.valid) {
+      if (CHAIN && tb.valid) {
         sincos_from_base<R>(tb, th, s, c);
       } else {
         Math<R>::sincos(th, s, c);

@@ -9,6 +9,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "cartpole_device.hpp"
 #include "double_pendulum_gen.hpp"
 #include "single_pendulum_gen.hpp"
@@ -62,7 +64,7 @@ struct SingleModelHandWritten {
 
 // models without anything to share between the stages of a step
 struct NoStepCache {
-  bool valid = false;
+  __device__ __forceinline__ void invalidate() {}
 };
 // the same model on the generated code (README.md:60-71 "Changing the dynamics": edit the Lagrangian in
 // tools/gen_dynamics.py, run it, rebuild with -DCPMPC_GENERATED_SINGLE=1)
@@ -105,26 +107,53 @@ using SingleModel = SingleModelHandWritten<R>;
 // cart + double pole: symbolic/dynamics_double.py:25-148 (generated terms, numeric 3x3 solve)
 //   a = M^-1 F,  da/dx_c = M^-1 (dF/dx_c - dM/dx_c a),  da/du = M^-1 e_0.  No dissipation, no
 //   external forces (HAS_EXT is ignored).
+// Round 6 (the 4-state model's instruction diet, through the generator): the parameter-only coefficients of the generated
+// terms are folded once per parameter set (DoublePendulumGenConsts, host / kernel-argument segment) together with 1 / M_00,
+// which is a parameter too; the generated code takes the poles' sines and cosines as INPUTS, so stages 2-4 of an RK4 step
+// get both pairs by one rotation each from stage 1's (StepCache = two TrigBase: 8 full fp64 sincos per step -> 2); entries
+// of dF/dx and dM/dth that vanish identically are neither written nor read (DoublePendulumGenSparsity), and the columns of
+// da/dx that vanish identically -- b_x and b_x' do not enter these dynamics -- are known to the RK4 sensitivity chain
+// (kJaZeroCols: a third of its multiply-adds were products with those zeros).
 // ------------------------------------------------------------------------------------------------
+#ifndef CPMPC_DOUBLE_TRIG_ROTATE
+#define CPMPC_DOUBLE_TRIG_ROTATE 1   // 0: a full sincos of both angles at every RK4 stage (A/B)
+#endif
+// as CPMPC_F64_TRIG_CHAIN (cartpole_device.hpp) for this model: 2 = the rollouts of the fused kernel evaluate both base pairs in
+// full once (chain_begin) and stage 1 of every step rotates from the previous step's pair
+#ifndef CPMPC_DOUBLE_TRIG_CHAIN
+#define CPMPC_DOUBLE_TRIG_CHAIN 0
+#endif
+#ifndef CPMPC_JA_ZERO_COLS
+#define CPMPC_JA_ZERO_COLS 1         // 0: the sensitivity chain multiplies through the identically-zero columns (A/B)
+#endif
 template <typename R>
 struct DoubleConsts {
-  R p[6];  // m_b, m_1, m_2, l_1, l_2, g
+  DoublePendulumGenConsts<R> g;  // generated: coefficients of the terms
+  R inv_m00;                     // 1 / (m_b + m_1 + m_2): the first pivot of the mass matrix is a parameter
+};
+template <typename R>
+struct DoubleTrig {
+  TrigBase<R> t1, t2;
+  __device__ __forceinline__ void invalidate() { t1.valid = t2.valid = false; }
 };
 
 template <typename R>
 struct DoubleModel {
   static constexpr int NX = 6, NQ = 3, NP = 6;
   using Consts = DoubleConsts<R>;
+  using Sp = DoublePendulumGenSparsity;
+  static constexpr unsigned kJaZeroCols = CPMPC_JA_ZERO_COLS ? Sp::ja_zero_cols : 0u;
   template <typename P>
   __host__ __device__ static Consts make(const P* p) {
     Consts k;
-    for (int i = 0; i < 6; ++i) k.p[i] = R(p[i]);
+    k.g = double_pendulum_gen_consts<R, P>(p);
+    k.inv_m00 = R(P(1) / (p[0] + p[1] + p[2]));
     return k;
   }
-  // LDL^T of the symmetric positive definite 3x3 mass matrix
-  __device__ __forceinline__ static void factor(const R* M, R (&L)[3], R (&id)[3]) {
+  // LDL^T of the symmetric positive definite 3x3 mass matrix (its first pivot and that pivot's reciprocal are parameters)
+  __device__ __forceinline__ static void factor(const R* M, const R id0, R (&L)[3], R (&id)[3]) {
     const R d0 = M[0];
-    id[0] = Math<R>::rcp(d0);
+    id[0] = id0;
     L[0] = M[3] * id[0];
     L[1] = M[6] * id[0];
     const R d1 = M[4] - L[0] * L[0] * d0;
@@ -142,41 +171,99 @@ struct DoubleModel {
     y[1] = z1 * id[1] - L[2] * y[2];
     y[0] = z0 * id[0] - L[0] * y[1] - L[1] * y[2];
   }
-  template <bool WITH_J, bool HAS_EXT>
-  __device__ __forceinline__ static void accel(const Consts& k, const R (&x)[NX], const R u,
-                                               const ExtForce<R>&, R (&a)[NQ], R (&Ja)[NQ][NX],
-                                               R (&Jua)[NQ]) {
+  // the accelerations and their partials from the poles' sines and cosines
+  template <bool WITH_J>
+  __device__ __forceinline__ static void accel_sc(const Consts& k, const R s1, const R c1, const R s2, const R c2,
+                                                  const R (&x)[NX], const R u, R (&a)[NQ], R (&Ja)[NQ][NX], R (&Jua)[NQ]) {
     R M[9], F[3], dFdx[18], dM1[9], dM2[9], L[3], id[3];
-    double_pendulum_terms<R>(k.p, x, u, M, F, dFdx, dM1, dM2);
-    factor(M, L, id);
+    double_pendulum_terms_sc<R>(k.g, s1, c1, s2, c2, x, u, M, F, dFdx, dM1, dM2);
+    factor(M, k.inv_m00, L, id);
     solve(L, id, F[0], F[1], F[2], a);
     if (WITH_J) {
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
-        R r0 = dFdx[0 * 6 + c], r1 = dFdx[1 * 6 + c], r2 = dFdx[2 * 6 + c];
-        if (c == 1 || c == 2) {
-          const R* dM = (c == 1) ? dM1 : dM2;
-          r0 -= dM[0] * a[0] + dM[1] * a[1] + dM[2] * a[2];
-          r1 -= dM[3] * a[0] + dM[4] * a[1] + dM[5] * a[2];
-          r2 -= dM[6] * a[0] + dM[7] * a[1] + dM[8] * a[2];
+        if ((Sp::ja_zero_cols >> c) & 1u) {  // the state component does not enter the dynamics: da/dx_c = 0
+          Ja[0][c] = R(0);
+          Ja[1][c] = R(0);
+          Ja[2][c] = R(0);
+          continue;
+        }
+        // right-hand side dF/dx_c - (dM/dx_c) a, identically-zero entries left out
+        R r[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          bool have = Sp::dFdx[i * 6 + c];
+          R v = have ? dFdx[i * 6 + c] : R(0);
+          if (c == 1 || c == 2) {
+            const R* dM = (c == 1) ? dM1 : dM2;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+              const bool nz = (c == 1) ? Sp::dM1[i * 3 + j] : Sp::dM2[i * 3 + j];
+              if (nz) {
+                v = have ? v - dM[i * 3 + j] * a[j] : -(dM[i * 3 + j] * a[j]);
+                have = true;
+              }
+            }
+          }
+          r[i] = v;
         }
         R y[3];
-        solve(L, id, r0, r1, r2, y);
+        solve(L, id, r[0], r[1], r[2], y);
         Ja[0][c] = y[0];
         Ja[1][c] = y[1];
         Ja[2][c] = y[2];
       }
-      solve(L, id, R(1), R(0), R(0), Jua);
+      // M^-1 e_0: z = (1, -L0, -L1 + L2 L0)
+      const R z1 = -L[0];
+      const R z2 = -L[1] - L[2] * z1;
+      Jua[2] = z2 * id[2];
+      Jua[1] = z1 * id[1] - L[2] * Jua[2];
+      Jua[0] = id[0] - L[0] * Jua[1] - L[1] * Jua[2];
     }
   }
-  using StepCache = NoStepCache;
-  __device__ __forceinline__ static void chain_begin(StepCache&, const R (&)[NX]) {}
+  template <bool WITH_J, bool HAS_EXT>
+  __device__ __forceinline__ static void accel(const Consts& k, const R (&x)[NX], const R u,
+                                               const ExtForce<R>&, R (&a)[NQ], R (&Ja)[NQ][NX],
+                                               R (&Jua)[NQ]) {
+    R s1, c1, s2, c2;
+    Math<R>::sincos(x[1], s1, c1);
+    Math<R>::sincos(x[2], s2, c2);
+    accel_sc<WITH_J>(k, s1, c1, s2, c2, x, u, a, Ja, Jua);
+  }
+  // what the stages of an RK4 step (and consecutive steps of a rollout) share: both poles' sine / cosine pairs
+  using StepCache = DoubleTrig<R>;
+  __device__ __forceinline__ static void chain_begin(StepCache& sc, const R (&x)[NX]) {
+    if constexpr (Math<R>::kIncrementalTrig && CPMPC_DOUBLE_TRIG_ROTATE && CPMPC_DOUBLE_TRIG_CHAIN == 2) {
+      Math<R>::sincos(x[1], sc.t1.s0, sc.t1.c0);
+      Math<R>::sincos(x[2], sc.t2.s0, sc.t2.c0);
+      sc.t1.th0 = x[1];
+      sc.t2.th0 = x[2];
+      sc.t1.valid = sc.t2.valid = true;
+    }
+  }
   template <bool WITH_J, bool HAS_EXT, int STAGE>
   __device__ __forceinline__ static void accel_stage(const Consts& k, const R (&x)[NX], const R u,
                                                      const ExtForce<R>& fe, R (&a)[NQ], R (&Ja)[NQ][NX],
-                                                     R (&Jua)[NQ], StepCache&) {
-    accel<WITH_J, HAS_EXT>(k, x, u, fe, a, Ja, Jua);
+                                                     R (&Jua)[NQ], StepCache& sc) {
+    if constexpr (CPMPC_DOUBLE_TRIG_ROTATE) {
+      R s1, c1, s2, c2;
+      stage_sincos<R, STAGE, CPMPC_DOUBLE_TRIG_CHAIN>(sc.t1, x[1], s1, c1);
+      stage_sincos<R, STAGE, CPMPC_DOUBLE_TRIG_CHAIN>(sc.t2, x[2], s2, c2);
+      accel_sc<WITH_J>(k, s1, c1, s2, c2, x, u, a, Ja, Jua);
+    } else {
+      accel<WITH_J, HAS_EXT>(k, x, u, fe, a, Ja, Jua);
+    }
   }
+};
+
+// columns of da/dx that vanish identically for the model (a bit mask; models without the knowledge: none)
+template <typename M, typename = void>
+struct JaZeroCols {
+  static constexpr unsigned value = 0u;
+};
+template <typename M>
+struct JaZeroCols<M, std::void_t<decltype(M::kJaZeroCols)>> {
+  static constexpr unsigned value = M::kJaZeroCols;
 };
 
 // pole angles are components 1..NQ-1 (wrapped to (-pi, pi]); component 0 is the base position (clamped)
@@ -189,7 +276,7 @@ __host__ __device__ constexpr bool is_angle(int t) {
 // RK4 without sensitivities (integration.hpp:52-62).  x updated in place.
 // ------------------------------------------------------------------------------------------------
 // `sc` carries what consecutive steps of one rollout can share (models.hpp: StepCache): pass the same object to every
-// step of the rollout, start a new rollout with sc.valid = false.
+// step of the rollout, start a new rollout with a fresh object (or sc.invalidate()).
 template <typename R, typename M, bool HAS_EXT>
 __device__ __forceinline__ void rk4_step_m(const typename M::Consts& k, const R h, R (&x)[M::NX], const R u,
                                            const ExtForce<R>& fe, typename M::StepCache& sc) {
@@ -235,34 +322,46 @@ __device__ __forceinline__ void rk4_step_m(const typename M::Consts& k, const R 
   rk4_step_m<R, M, HAS_EXT>(k, h, x, u, fe, sc);
 }
 
+template <int NX>
+__host__ __device__ constexpr int first_nonzero_col(unsigned zmask) {
+  for (int c = 0; c < NX; ++c)
+    if (!((zmask >> c) & 1u)) return c;
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // RK4 with sensitivities A = dx+/dx (NX x NX), Bv = dx+/du (NX)   (integration.hpp:13-49).
 //   D_1 = K_1,  D_{j+1} = K_{j+1} (I + a_j D_j),  a = {h/2, h/2, h},  A = I + h/6 (D_1 + 2 D_2 + 2 D_3 + D_4)
 // With K = [[0 I],[Ja]] the top NQ rows of K X are the bottom NQ rows of X and the bottom NQ rows are
 // Ja X, so each stage product costs NQ*NX*NX multiply-adds instead of NX^3.
 // ------------------------------------------------------------------------------------------------
-template <typename R, int NX, int NQ>
+// ZMASK: bit c set = column c of Ja vanishes identically for the model (JaZeroCols): its products are not issued and its
+// entry is not added (the compiler may not drop a multiplication by a value it cannot prove finite).
+template <typename R, int NX, int NQ, unsigned ZMASK = 0u>
 __device__ __forceinline__ void stage_chain_m(const R (&Ja)[NQ][NX], const R (&Jua)[NQ], const R a,
                                               const R (&D)[NX][NX], const R (&d)[NX], R (&Dn)[NX][NX],
                                               R (&dn)[NX]) {
+  constexpr int k0 = first_nonzero_col<NX>(ZMASK);
 #pragma unroll
   for (int c = 0; c < NX; ++c) {
 #pragma unroll
     for (int r = 0; r < NQ; ++r) Dn[r][c] = a * D[NQ + r][c] + (c == NQ + r ? R(1) : R(0));
 #pragma unroll
     for (int r = 0; r < NQ; ++r) {
-      R acc = Ja[r][0] * D[0][c];
+      R acc = Ja[r][k0] * D[k0][c];
 #pragma unroll
-      for (int kk = 1; kk < NX; ++kk) acc += Ja[r][kk] * D[kk][c];
-      Dn[NQ + r][c] = Ja[r][c] + a * acc;
+      for (int kk = k0 + 1; kk < NX; ++kk)
+        if (!((ZMASK >> kk) & 1u)) acc += Ja[r][kk] * D[kk][c];
+      Dn[NQ + r][c] = ((ZMASK >> c) & 1u) ? a * acc : Ja[r][c] + a * acc;
     }
   }
 #pragma unroll
   for (int r = 0; r < NQ; ++r) {
     dn[r] = a * d[NQ + r];
-    R acc = Ja[r][0] * d[0];
+    R acc = Ja[r][k0] * d[k0];
 #pragma unroll
-    for (int kk = 1; kk < NX; ++kk) acc += Ja[r][kk] * d[kk];
+    for (int kk = k0 + 1; kk < NX; ++kk)
+      if (!((ZMASK >> kk) & 1u)) acc += Ja[r][kk] * d[kk];
     dn[NQ + r] = a * acc + Jua[r];
   }
 }
@@ -271,35 +370,46 @@ __device__ __forceinline__ void stage_chain_m(const R (&Ja)[NQ][NX], const R (&J
 // with the zeros and ones of the top rows are not issued (the compiler may not drop a multiplication by a literal 0.0 on
 // its own: 0 * inf).  Same operations in the same order on everything that is not such a constant, so a finite result has
 // the bits stage_chain_m gives.
-template <typename R, int NX, int NQ>
+template <typename R, int NX, int NQ, unsigned ZMASK = 0u>
 __device__ __forceinline__ void stage_chain_first_m(const R (&Ja)[NQ][NX], const R (&Jua)[NQ], const R a,
                                                     const R (&Ja1)[NQ][NX], const R (&Jua1)[NQ], R (&Dn)[NX][NX],
                                                     R (&dn)[NX]) {
+  // D_1's rows: top r = e_{NQ + r}, bottom r = Ja1[r].  (Ja D_1)[r][c] = sum_kk<NQ Ja[r][kk] [c == NQ + kk] + sum_kk Ja[r][NQ + kk] Ja1[kk][c]
 #pragma unroll
   for (int c = 0; c < NX; ++c) {
+    const bool czero = (ZMASK >> c) & 1u;   // then Ja1[.][c] = Ja[.][c] = 0
 #pragma unroll
-    for (int r = 0; r < NQ; ++r) Dn[r][c] = a * Ja1[r][c] + (c == NQ + r ? R(1) : R(0));
+    for (int r = 0; r < NQ; ++r) Dn[r][c] = czero ? (c == NQ + r ? R(1) : R(0)) : a * Ja1[r][c] + (c == NQ + r ? R(1) : R(0));
 #pragma unroll
     for (int r = 0; r < NQ; ++r) {
-      R acc;
-      if (c >= NQ) {
+      bool have = false;
+      R acc = R(0);
+      if (c >= NQ && !((ZMASK >> (c - NQ)) & 1u)) {
         acc = Ja[r][c - NQ];  // the one of the identity block
-#pragma unroll
-        for (int kk = 0; kk < NQ; ++kk) acc += Ja[r][NQ + kk] * Ja1[kk][c];
-      } else {
-        acc = Ja[r][NQ] * Ja1[0][c];
-#pragma unroll
-        for (int kk = 1; kk < NQ; ++kk) acc += Ja[r][NQ + kk] * Ja1[kk][c];
+        have = true;
       }
-      Dn[NQ + r][c] = Ja[r][c] + a * acc;
+      if (!czero) {
+#pragma unroll
+        for (int kk = 0; kk < NQ; ++kk) {
+          if ((ZMASK >> (NQ + kk)) & 1u) continue;
+          acc = have ? acc + Ja[r][NQ + kk] * Ja1[kk][c] : Ja[r][NQ + kk] * Ja1[kk][c];
+          have = true;
+        }
+      }
+      Dn[NQ + r][c] = czero ? (have ? a * acc : R(0)) : (have ? Ja[r][c] + a * acc : Ja[r][c]);
     }
   }
 #pragma unroll
   for (int r = 0; r < NQ; ++r) {
     dn[r] = a * Jua1[r];
-    R acc = Ja[r][NQ] * Jua1[0];
+    bool have = false;
+    R acc = R(0);
 #pragma unroll
-    for (int kk = 1; kk < NQ; ++kk) acc += Ja[r][NQ + kk] * Jua1[kk];
+    for (int kk = 0; kk < NQ; ++kk) {
+      if ((ZMASK >> (NQ + kk)) & 1u) continue;
+      acc = have ? acc + Ja[r][NQ + kk] * Jua1[kk] : Ja[r][NQ + kk] * Jua1[kk];
+      have = true;
+    }
     dn[NQ + r] = a * acc + Jua[r];
   }
 }
@@ -313,6 +423,7 @@ __device__ __forceinline__ void rk4_step_jac_m(const typename M::Consts& k, cons
                                                const R u, const ExtForce<R>& fe, R (&A)[M::NX][M::NX],
                                                R (&Bv)[M::NX], typename M::StepCache& sc) {
   constexpr int NX = M::NX, NQ = M::NQ;
+  constexpr unsigned ZM = JaZeroCols<M>::value;
   const R hh = h / R(2);
   R Ja[NQ][NX], Jua[NQ];
   R D[NX][NX], d[NX], Dn[NX][NX], dn[NX];
@@ -355,11 +466,11 @@ __device__ __forceinline__ void rk4_step_jac_m(const typename M::Consts& k, cons
       Jua1[r] = Jua[r];
     }
     M::template accel_stage<true, HAS_EXT, 2>(k, xt, u, fe, a2, Ja, Jua, sc);
-    stage_chain_first_m<R, NX, NQ>(Ja, Jua, hh, Ja1, Jua1, Dn, dn);
+    stage_chain_first_m<R, NX, NQ, ZM>(Ja, Jua, hh, Ja1, Jua1, Dn, dn);
   }
 #else
   M::template accel_stage<true, HAS_EXT, 2>(k, xt, u, fe, a2, Ja, Jua, sc);
-  stage_chain_m<R, NX, NQ>(Ja, Jua, hh, D, d, Dn, dn);
+  stage_chain_m<R, NX, NQ, ZM>(Ja, Jua, hh, D, d, Dn, dn);
 #endif
 #pragma unroll
   for (int r = 0; r < NX; ++r) {
@@ -380,7 +491,7 @@ __device__ __forceinline__ void rk4_step_jac_m(const typename M::Consts& k, cons
     xt[NQ + i] = v3[i];
   }
   M::template accel_stage<true, HAS_EXT, 3>(k, xt, u, fe, a3, Ja, Jua, sc);
-  stage_chain_m<R, NX, NQ>(Ja, Jua, hh, D, d, Dn, dn);
+  stage_chain_m<R, NX, NQ, ZM>(Ja, Jua, hh, D, d, Dn, dn);
 #pragma unroll
   for (int r = 0; r < NX; ++r) {
 #pragma unroll
@@ -400,7 +511,7 @@ __device__ __forceinline__ void rk4_step_jac_m(const typename M::Consts& k, cons
     xt[NQ + i] = v4[i];
   }
   M::template accel_stage<true, HAS_EXT, 4>(k, xt, u, fe, a4, Ja, Jua, sc);
-  stage_chain_m<R, NX, NQ>(Ja, Jua, h, D, d, Dn, dn);
+  stage_chain_m<R, NX, NQ, ZM>(Ja, Jua, h, D, d, Dn, dn);
 
   const R h6 = h / R(6);
 #pragma unroll
@@ -414,124 +525,6 @@ __device__ __forceinline__ void rk4_step_jac_m(const typename M::Consts& k, cons
     const R v1 = x[NQ + i];
     x[i] += h6 * (v1 + v2[i] * R(2) + v3[i] * R(2) + v4[i]);
     x[NQ + i] += h6 * (a1[i] + a2[i] * R(2) + a3[i] * R(2) + a4[i]);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// The same sensitivities WITHOUT forming A (round 5, the 6-state model in the fused kernel).  rk4_step_jac_m holds three
-// NX x NX blocks (D_j, D_{j+1}, their weighted sum) next to the stage Jacobian while it builds A, and the caller a fourth
-// and fifth (Phi and A Phi): with NX = 6 that is ~180 values live at the peak, more than the float kernel's 256-register
-// budget for two waves per SIMD allows and, in double, the source of a third of the step's instructions
-// (accumulation-register traffic of the spills).  Here the step keeps only what the chain rule needs -- the four stage
-// Jacobians Ja_j (NQ x NX) and Jua_j (NQ) -- and every direction is then pushed through the four stages ON ITS OWN:
-//     w_j = Ja_j z_{j-1} (+ Jua_j),   z_0 = v,   z_j = v + a_j [ (z_{j-1})_bottom ; w_j ],   a = {h/2, h/2, h}
-//     v+_top    = v_top + h v_bottom + h^2/6 (w_1 + w_2 + w_3)
-//     v+_bottom = v_bottom + h/6 (w_1 + 2 w_2 + 2 w_3 + w_4)
-// (the top NQ rows of K z are the bottom rows of z, so only the bottoms w_j are ever computed).  The columns of Phi, the
-// earlier columns of Gamma and the new column B (v = 0, w_j += Jua_j) are such directions: ~110 multiply-adds each instead
-// of 36 for a product with a formed A, 84 + 21 live values instead of ~180.  Same mathematics as integration.hpp:36-46,
-// another order of the sums.
-// ------------------------------------------------------------------------------------------------
-template <typename R, typename M, bool HAS_EXT>
-__device__ __forceinline__ void rk4_step_stages_m(const typename M::Consts& k, const R h, R (&x)[M::NX], const R u,
-                                                  const ExtForce<R>& fe, R (&JaS)[4][M::NQ][M::NX], R (&JuaS)[4][M::NQ],
-                                                  typename M::StepCache& sc) {
-  constexpr int NX = M::NX, NQ = M::NQ;
-  R a1[NQ], a2[NQ], a3[NQ], a4[NQ], v2[NQ], v3[NQ], v4[NQ], xt[NX];
-  const R hh = h / R(2);
-  M::template accel_stage<true, HAS_EXT, 1>(k, x, u, fe, a1, JaS[0], JuaS[0], sc);
-#pragma unroll
-  for (int i = 0; i < NQ; ++i) {
-    v2[i] = x[NQ + i] + a1[i] * hh;
-    xt[i] = x[i] + x[NQ + i] * hh;
-    xt[NQ + i] = v2[i];
-  }
-  M::template accel_stage<true, HAS_EXT, 2>(k, xt, u, fe, a2, JaS[1], JuaS[1], sc);
-#pragma unroll
-  for (int i = 0; i < NQ; ++i) {
-    v3[i] = x[NQ + i] + a2[i] * hh;
-    xt[i] = x[i] + v2[i] * hh;
-    xt[NQ + i] = v3[i];
-  }
-  M::template accel_stage<true, HAS_EXT, 3>(k, xt, u, fe, a3, JaS[2], JuaS[2], sc);
-#pragma unroll
-  for (int i = 0; i < NQ; ++i) {
-    v4[i] = x[NQ + i] + a3[i] * h;
-    xt[i] = x[i] + v3[i] * h;
-    xt[NQ + i] = v4[i];
-  }
-  M::template accel_stage<true, HAS_EXT, 4>(k, xt, u, fe, a4, JaS[3], JuaS[3], sc);
-  const R h6 = h / R(6);
-#pragma unroll
-  for (int i = 0; i < NQ; ++i) {
-    const R v1 = x[NQ + i];
-    x[i] += h6 * (v1 + v2[i] * R(2) + v3[i] * R(2) + v4[i]);
-    x[NQ + i] += h6 * (a1[i] + a2[i] * R(2) + a3[i] * R(2) + a4[i]);
-  }
-}
-
-// one direction through the four stages, in place.  WITH_U: the direction of the control (v = 0 on entry is assumed and v
-// is overwritten with B = dx+/du).
-template <typename R, int NX, int NQ, bool WITH_U>
-__device__ __forceinline__ void rk4_push_direction(const R (&JaS)[4][NQ][NX], const R (&JuaS)[4][NQ], const R h, R (&v)[NX]) {
-  const R hh = h / R(2);
-  R zt[NQ], zb[NQ], w[NQ], s3[NQ], s6[NQ];  // z_{j-1} (top, bottom), w_j, w_1 + w_2 + w_3, w_1 + 2 w_2 + 2 w_3 + w_4
-  // stage 1: z_0 = v
-#pragma unroll
-  for (int r = 0; r < NQ; ++r) {
-    if constexpr (WITH_U) {
-      w[r] = JuaS[0][r];
-    } else {
-      R acc = JaS[0][r][0] * v[0];
-#pragma unroll
-      for (int c = 1; c < NX; ++c) acc += JaS[0][r][c] * v[c];
-      w[r] = acc;
-    }
-    s3[r] = w[r];
-    s6[r] = w[r];
-  }
-  // stages 2 .. 4
-#pragma unroll
-  for (int j = 1; j < 4; ++j) {
-    const R a = (j == 3) ? h : hh;
-#pragma unroll
-    for (int r = 0; r < NQ; ++r) {
-      if constexpr (WITH_U) {
-        zt[r] = (j == 1) ? R(0) : a * zb[r];  // (z_0)_bottom = 0
-      } else {
-        zt[r] = v[r] + a * ((j == 1) ? v[NQ + r] : zb[r]);
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < NQ; ++r) zb[r] = WITH_U ? a * w[r] : v[NQ + r] + a * w[r];
-#pragma unroll
-    for (int r = 0; r < NQ; ++r) {
-      R acc = JaS[j][r][NQ] * zb[0];
-#pragma unroll
-      for (int c = 1; c < NQ; ++c) acc += JaS[j][r][NQ + c] * zb[c];
-      if (!(WITH_U && j == 1)) {  // (z_1)_top = 0 for the control's direction
-#pragma unroll
-        for (int c = 0; c < NQ; ++c) acc += JaS[j][r][c] * zt[c];
-      }
-      if constexpr (WITH_U) acc += JuaS[j][r];
-      w[r] = acc;
-    }
-#pragma unroll
-    for (int r = 0; r < NQ; ++r) {
-      if (j < 3) s3[r] += w[r];
-      s6[r] += (j < 3) ? w[r] * R(2) : w[r];
-    }
-  }
-  const R h6 = h / R(6), hh6 = h * h6;
-#pragma unroll
-  for (int r = 0; r < NQ; ++r) {
-    if constexpr (WITH_U) {
-      v[r] = hh6 * s3[r];
-      v[NQ + r] = h6 * s6[r];
-    } else {
-      v[r] = (v[r] + h * v[NQ + r]) + hh6 * s3[r];
-      v[NQ + r] = v[NQ + r] + h6 * s6[r];
-    }
   }
 }
 

@@ -199,11 +199,6 @@ __device__ __forceinline__ R group_last(R v, int gbase) {
 #ifndef CPMPC_EXIT_FLOOR_F64
 #define CPMPC_EXIT_FLOOR_F64 0
 #endif
-// 1 (default): the linearisation of the 6-state model pushes every direction (the columns of Phi and Gamma, B) through the
-// four RK4 stages on its own instead of forming A and multiplying (models.hpp: rk4_step_stages_m / rk4_push_direction)
-#ifndef CPMPC_FUSED_COLUMNWISE
-#define CPMPC_FUSED_COLUMNWISE 0
-#endif
 // 1: the float 4-state kernels carry the whole terminal part of the QP in double (mpc_fused_body.inc: kWideQP); measured in
 // round 5, see HISTORY.md
 #ifndef CPMPC_FUSED_WIDE_QP_F32

@@ -1280,7 +1280,7 @@ __global__ __launch_bounds__(CPMPC_PF_BLOCK) void finalize_kernel(const SolverAr
       const R u = u_next;
       if (kk + 1 < a.N) u_next = a.zu[(int64_t)(kk + 1) * st + p];
       if (a.u_out) a.u_out[(int64_t)kk * ob + p] = u;
-      if (kk % 8 == 0) chain.valid = false;  // re-anchor the sine / cosine chain with a full evaluation every 8 steps
+      if (kk % 8 == 0) chain.invalidate();  // re-anchor the sine / cosine chain with a full evaluation every 8 steps
       rk4_step_m<R, M, false>(k, a.dt, x, u, fe, chain);
       wrap_angles<R, M>(x);
 #pragma unroll
@@ -1434,7 +1434,7 @@ __global__ __launch_bounds__(64) void sim_kernel(int64_t B, typename M::Consts k
   typename M::StepCache chain;
   for (int i = 0; i < n_sub; ++i) {
     const R h = (i + 1 == n_sub) ? h_last : internal_dt;
-    if (i % 8 == 0) chain.valid = false;  // re-anchor the sine / cosine chain every 8 sub-steps
+    if (i % 8 == 0) chain.invalidate();  // re-anchor the sine / cosine chain every 8 sub-steps
     rk4_step_m<R, M, true>(k, h, xs, uu, fe, chain);
     wrap_angles<R, M>(xs);
   }

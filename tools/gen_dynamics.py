@@ -164,6 +164,147 @@ def emit(model, scalar, header):
     return "\n".join(lines) + "\n"
 
 
+def emit_hip_sc(model, header):
+    """The HIP form of a mass-matrix model (round 6): what the hand-written 4-state model has, from the generator --
+      * every output is read as a polynomial in the per-lane atoms (sines / cosines of the angles and of their differences,
+        velocities, the control); its coefficients depend on the parameters only and are folded into a constants struct
+        evaluated once (on the host, in the host's precision) by <name>_gen_consts(): kernel-argument segment / SGPRs,
+      * the sines and cosines of the angles are INPUTS (<name>_terms_sc), so that the stages of an RK4 step can take them
+        by one rotation from stage 1's pair (models.hpp: StepCache); sin / cos of an angle difference is one product pair,
+      * the structure of the outputs as compile-time masks (<Name>GenSparsity): entries that are identically zero are
+        neither written nor read by the solver next to this code, columns of da/dx that vanish identically (a state that
+        does not enter the dynamics) are known to the RK4 sensitivity chain (models.hpp: stage_chain_m)."""
+    nq, q, qd, u, M, F = model["nq"], model["q"], model["qd"], model["u"], model["M"], model["F"]
+    name = model["name"]
+    cname = "".join(w.capitalize() for w in name.split("_"))
+    x = q + qd
+    nx = 2 * nq
+    outs = []
+    for i in range(nq):
+        for j in range(nq):
+            outs.append(("M[%d]" % (i * nq + j), M[i, j]))
+    for i in range(nq):
+        outs.append(("F[%d]" % i, F[i]))
+    for i in range(nq):
+        for c in range(nx):
+            outs.append(("dFdx[%d]" % (i * nx + c), sp.diff(F[i], x[c])))
+    for n, j in enumerate(model["angles"]):
+        for i in range(nq):
+            for k in range(nq):
+                outs.append(("dM%d[%d]" % (n + 1, i * nq + k), sp.diff(M[i, k], q[j])))
+    # per-lane atoms: trig of the angles (inputs) and of their differences (one product pair each, emitted first)
+    atoms, pre = {}, []
+    for j in model["angles"]:
+        sj, cj = sp.symbols("s%d c%d" % (j, j), real=True)
+        atoms[sp.sin(q[j])] = sj
+        atoms[sp.cos(q[j])] = cj
+    ang = model["angles"]
+    for ia in range(len(ang)):
+        for ib in range(ia + 1, len(ang)):
+            i, j = ang[ia], ang[ib]
+            sd, cd = sp.symbols("sd%d%d cd%d%d" % (i, j, i, j), real=True)
+            si, ci, sj, cj = atoms[sp.sin(q[i])], atoms[sp.cos(q[i])], atoms[sp.sin(q[j])], atoms[sp.cos(q[j])]
+            atoms[sp.sin(q[i] - q[j])] = sd
+            atoms[sp.cos(q[i] - q[j])] = cd
+            atoms[sp.sin(q[j] - q[i])] = -sd
+            atoms[sp.cos(q[j] - q[i])] = cd
+            pre.append((sd, si * cj - ci * sj))
+            pre.append((cd, ci * cj + si * sj))
+    lane_syms = [v for v in atoms.values() if v.is_Symbol] + list(qd) + [u]
+    lane_syms = list(dict.fromkeys(lane_syms))
+    kconst = {}     # canonical parameter-only expression -> constant symbol
+
+    def const_of(e):
+        e = sp.factor(e)
+        num, rest = e.as_coeff_Mul()
+        if rest == 1:
+            return sp.Integer(1), num
+        key = sp.expand(rest)
+        lead = sp.Poly(key, *model["params"]).coeffs()[0]
+        if lead < 0:                      # one constant for +k and -k
+            key, num = -key, -num
+        if key not in kconst:
+            kconst[key] = sp.Symbol("k%d" % len(kconst), real=True)
+        return kconst[key], num
+
+    lane_exprs = []
+    for _, e in outs:
+        e = sp.expand(e.subs(atoms))
+        if e.has(sp.sin) or e.has(sp.cos):
+            raise ValueError("trigonometric term outside the atoms: %s" % e)
+        if e == 0:
+            lane_exprs.append(sp.Integer(0))
+            continue
+        poly = sp.Poly(e, *lane_syms)
+        acc = 0
+        for mono, coeff in poly.terms():
+            ksym, num = const_of(coeff)
+            term = num * ksym
+            for sym, pw in zip(lane_syms, mono):
+                term = term * sym**pw
+            acc = acc + term
+        lane_exprs.append(acc)
+    repl, red = sp.cse(lane_exprs, symbols=sp.numbered_symbols("t"), optimizations="basic")
+    names = [n for n, _ in outs]
+    pr, prc = _Printer("R"), _Printer("P")
+    const_syms = list(kconst.values())
+    lines = list(header)
+    lines += ["template <typename R>", "struct %sGenConsts {" % cname, "  R k[%d];" % max(len(const_syms), 1), "};",
+              "// the parameter-only coefficients, once per parameter set (host: in double; per-problem parameters: per lane)",
+              "template <typename R, typename P>",
+              "__host__ __device__ inline %sGenConsts<R> %s_gen_consts(const P* p) {" % (cname, name), "  %sGenConsts<R> K;" % cname]
+    for i, sym in enumerate(model["params"]):
+        lines.append("  const P %s = p[%d];" % (sym, i))
+    for i, (ce, sym) in enumerate(kconst.items()):
+        lines.append("  K.k[%d] = R(%s);" % (i, prc.doprint(ce)))
+    lines.append("  " + " ".join("(void)%s;" % s_ for s_ in model["params"]))
+    lines += ["  return K;", "}"]
+    nz = {n: (e != 0) for n, e in zip(names, red)}
+
+    def mask(prefix, count):
+        return "{" + ", ".join("true" if nz["%s[%d]" % (prefix, i)] else "false" for i in range(count)) + "}"
+
+    ja_zero = []
+    for c in range(nx):
+        z = all(not nz["dFdx[%d]" % (i * nx + c)] for i in range(nq))
+        if c in model["angles"]:
+            n_ = model["angles"].index(c) + 1
+            z = z and all(not nz["dM%d[%d]" % (n_, i)] for i in range(nq * nq))
+        ja_zero.append(z)
+    lines += ["// which outputs are not identically zero (the others are never written: do not read them), and the columns of",
+              "// da/dx that vanish identically (bit c: state component c does not enter the dynamics)",
+              "struct %sGenSparsity {" % cname,
+              "  static constexpr bool dFdx[%d] = %s;" % (nq * nx, mask("dFdx", nq * nx))]
+    for n_ in range(len(model["angles"])):
+        lines.append("  static constexpr bool dM%d[%d] = %s;" % (n_ + 1, nq * nq, mask("dM%d" % (n_ + 1), nq * nq)))
+    lines += ["  static constexpr unsigned ja_zero_cols = 0x%xu;" % sum(1 << c for c in range(nx) if ja_zero[c]), "};"]
+    args = ", ".join("const R s%d, const R c%d" % (j, j) for j in model["angles"])
+    lines += ["template <typename R>",
+              "__device__ __forceinline__ void %s_terms_sc(const %sGenConsts<R>& K, %s, const R* x, const R u, R* M, R* F, "
+              "R* dFdx, R* dM1, R* dM2) {" % (name, cname, args)]
+    used = set()
+    for _, e in repl:
+        used |= e.free_symbols
+    for e in red:
+        used |= e.free_symbols
+    for i, sym in enumerate(x):
+        if sym in used:
+            lines.append("  const R %s = x[%d];" % (sym, i))
+    for i, sym in enumerate(const_syms):
+        lines.append("  const R %s = K.k[%d];" % (sym, i))
+    for sym, e in pre:
+        if sym in used:
+            lines.append("  const R %s = %s;" % (sym, pr.doprint(e)))
+    for sym, e in repl:
+        lines.append("  const R %s = %s;" % (sym, pr.doprint(e)))
+    for n, e in zip(names, red):
+        if e != 0:
+            lines.append("  %s = %s;" % (n, pr.doprint(e)))
+    lines.append("  (void)x; (void)u; (void)dFdx; (void)dM1; (void)dM2;")
+    lines.append("}")
+    return "\n".join(lines) + "\n"
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # cart + single pole with dissipation, springs and external forces (symbolic/dynamics_single.py:58-143)
 # ------------------------------------------------------------------------------------------------------------------
@@ -413,7 +554,9 @@ def main():
               "// p = {m_b, m_1, m_2, l_1, l_2, g}; x = {b_x, th_1, th_2, b_x', th_1', th_2'}."]
     c_code = emit(model, "double", banner)
     write_if_changed(os.path.join(ROOT, "oracle", "double_pendulum_gen.inc"), c_code)
-    hip = emit(model, "R", banner + ["#pragma once", "namespace cpmpc {"]) + "}  // namespace cpmpc\n"
+    hip = (emit(model, "R", banner + ["#pragma once", "namespace cpmpc {"])
+           + emit_hip_sc(model, ["// ---- round 6: the same terms with constants folded, trigonometry as inputs and the structure as masks ----"])
+           + "}  // namespace cpmpc\n")
     write_if_changed(os.path.join(ROOT, "cart-pole-mpc_amd", "csrc", "double_pendulum_gen.hpp"), hip)
     single = derive_single()
     files = write_single(single)
