@@ -329,6 +329,24 @@ __host__ __device__ constexpr int first_nonzero_col(unsigned zmask) {
   return 0;
 }
 
+// Columns of the step Jacobian A = dx+/dx that are known in closed form.  A state component c that does not enter the
+// dynamics (zmask bit c: Ja[:, c] = 0 at every stage) gives, by D_1 = K_1, D_{j+1} = K_{j+1} (I + a_j D_j):
+//   a position c < NQ:                                   D_j[:, c] = 0       for every stage,  A[:, c] = e_c
+//   a velocity c = NQ + r whose position r is such too:  D_j[:, c] = e_r     for every stage,  A[:, c] = e_c + h e_r
+// so the chain neither computes nor stores those columns, and products with A take them as the 0, 1 and h they are.
+template <int NX, int NQ>
+__host__ __device__ constexpr unsigned trivial_cols(unsigned zmask) {
+  unsigned t = 0;
+  for (int c = 0; c < NX; ++c) {
+    if (!((zmask >> c) & 1u)) continue;
+    if (c < NQ || ((zmask >> (c - NQ)) & 1u)) t |= 1u << c;
+  }
+  return t;
+}
+#ifndef CPMPC_JA_TRIVIAL_COLS
+#define CPMPC_JA_TRIVIAL_COLS 1   // 0: the chain carries the identically-known columns like any other (A/B)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // RK4 with sensitivities A = dx+/dx (NX x NX), Bv = dx+/du (NX)   (integration.hpp:13-49).
 //   D_1 = K_1,  D_{j+1} = K_{j+1} (I + a_j D_j),  a = {h/2, h/2, h},  A = I + h/6 (D_1 + 2 D_2 + 2 D_3 + D_4)
@@ -342,8 +360,10 @@ __device__ __forceinline__ void stage_chain_m(const R (&Ja)[NQ][NX], const R (&J
                                               const R (&D)[NX][NX], const R (&d)[NX], R (&Dn)[NX][NX],
                                               R (&dn)[NX]) {
   constexpr int k0 = first_nonzero_col<NX>(ZMASK);
+  constexpr unsigned TRIV = CPMPC_JA_TRIVIAL_COLS ? trivial_cols<NX, NQ>(ZMASK) : 0u;
 #pragma unroll
   for (int c = 0; c < NX; ++c) {
+    if ((TRIV >> c) & 1u) continue;  // known in closed form: neither computed nor stored
 #pragma unroll
     for (int r = 0; r < NQ; ++r) Dn[r][c] = a * D[NQ + r][c] + (c == NQ + r ? R(1) : R(0));
 #pragma unroll
@@ -375,8 +395,10 @@ __device__ __forceinline__ void stage_chain_first_m(const R (&Ja)[NQ][NX], const
                                                     const R (&Ja1)[NQ][NX], const R (&Jua1)[NQ], R (&Dn)[NX][NX],
                                                     R (&dn)[NX]) {
   // D_1's rows: top r = e_{NQ + r}, bottom r = Ja1[r].  (Ja D_1)[r][c] = sum_kk<NQ Ja[r][kk] [c == NQ + kk] + sum_kk Ja[r][NQ + kk] Ja1[kk][c]
+  constexpr unsigned TRIV = CPMPC_JA_TRIVIAL_COLS ? trivial_cols<NX, NQ>(ZMASK) : 0u;
 #pragma unroll
   for (int c = 0; c < NX; ++c) {
+    if ((TRIV >> c) & 1u) continue;
     const bool czero = (ZMASK >> c) & 1u;   // then Ja1[.][c] = Ja[.][c] = 0
 #pragma unroll
     for (int r = 0; r < NQ; ++r) Dn[r][c] = czero ? (c == NQ + r ? R(1) : R(0)) : a * Ja1[r][c] + (c == NQ + r ? R(1) : R(0));
@@ -424,6 +446,7 @@ __device__ __forceinline__ void rk4_step_jac_m(const typename M::Consts& k, cons
                                                R (&Bv)[M::NX], typename M::StepCache& sc) {
   constexpr int NX = M::NX, NQ = M::NQ;
   constexpr unsigned ZM = JaZeroCols<M>::value;
+  constexpr unsigned TRIV = CPMPC_JA_TRIVIAL_COLS ? trivial_cols<NX, NQ>(ZM) : 0u;
   const R hh = h / R(2);
   R Ja[NQ][NX], Jua[NQ];
   R D[NX][NX], d[NX], Dn[NX][NX], dn[NX];
@@ -436,6 +459,7 @@ __device__ __forceinline__ void rk4_step_jac_m(const typename M::Consts& k, cons
   for (int r = 0; r < NQ; ++r) {
 #pragma unroll
     for (int c = 0; c < NX; ++c) {
+      if ((TRIV >> c) & 1u) continue;
       D[r][c] = (c == NQ + r ? R(1) : R(0));
       D[NQ + r][c] = Ja[r][c];
     }
@@ -445,7 +469,8 @@ __device__ __forceinline__ void rk4_step_jac_m(const typename M::Consts& k, cons
 #pragma unroll
   for (int r = 0; r < NX; ++r) {
 #pragma unroll
-    for (int c = 0; c < NX; ++c) As[r][c] = D[r][c];
+    for (int c = 0; c < NX; ++c)
+      if (!((TRIV >> c) & 1u)) As[r][c] = D[r][c];
     bs[r] = d[r];
   }
 
@@ -476,6 +501,7 @@ __device__ __forceinline__ void rk4_step_jac_m(const typename M::Consts& k, cons
   for (int r = 0; r < NX; ++r) {
 #pragma unroll
     for (int c = 0; c < NX; ++c) {
+      if ((TRIV >> c) & 1u) continue;
       As[r][c] += Dn[r][c] * R(2);
       D[r][c] = Dn[r][c];
     }
@@ -496,6 +522,7 @@ __device__ __forceinline__ void rk4_step_jac_m(const typename M::Consts& k, cons
   for (int r = 0; r < NX; ++r) {
 #pragma unroll
     for (int c = 0; c < NX; ++c) {
+      if ((TRIV >> c) & 1u) continue;
       As[r][c] += Dn[r][c] * R(2);
       D[r][c] = Dn[r][c];
     }
@@ -517,7 +544,10 @@ __device__ __forceinline__ void rk4_step_jac_m(const typename M::Consts& k, cons
 #pragma unroll
   for (int r = 0; r < NX; ++r) {
 #pragma unroll
-    for (int c = 0; c < NX; ++c) A[r][c] = (r == c ? R(1) : R(0)) + h6 * (As[r][c] + Dn[r][c]);
+    for (int c = 0; c < NX; ++c) {
+      if ((TRIV >> c) & 1u) A[r][c] = (r == c) ? R(1) : ((c >= NQ && r == c - NQ) ? h : R(0));  // e_c (+ h e_{c-NQ}): see trivial_cols
+      else A[r][c] = (r == c ? R(1) : R(0)) + h6 * (As[r][c] + Dn[r][c]);
+    }
     Bv[r] = h6 * (bs[r] + dn[r]);
   }
 #pragma unroll
@@ -525,6 +555,32 @@ __device__ __forceinline__ void rk4_step_jac_m(const typename M::Consts& k, cons
     const R v1 = x[NQ + i];
     x[i] += h6 * (v1 + v2[i] * R(2) + v3[i] * R(2) + v4[i]);
     x[NQ + i] += h6 * (a1[i] + a2[i] * R(2) + a3[i] * R(2) + a4[i]);
+  }
+}
+
+// y = A v for the step Jacobian A of rk4_step_jac_m<R, M> with step h: the columns of A that are known in closed form
+// (trivial_cols) enter as what they are -- v_c to row c, h v_c to row c - NQ -- and not as products with stored 0, 1, h.
+template <typename R, typename M>
+__device__ __forceinline__ void step_jac_apply(const R (&A)[M::NX][M::NX], const R h, const R (&v)[M::NX], R (&y)[M::NX]) {
+  constexpr int NX = M::NX, NQ = M::NQ;
+  constexpr unsigned TRIV = CPMPC_JA_TRIVIAL_COLS ? trivial_cols<NX, NQ>(JaZeroCols<M>::value) : 0u;
+#pragma unroll
+  for (int r = 0; r < NX; ++r) {
+    bool have = false;
+    R acc = R(0);
+#pragma unroll
+    for (int m = 0; m < NX; ++m) {
+      if ((TRIV >> m) & 1u) continue;
+      acc = have ? acc + A[r][m] * v[m] : A[r][m] * v[m];
+      have = true;
+    }
+#pragma unroll
+    for (int m = 0; m < NX; ++m) {
+      if (!((TRIV >> m) & 1u)) continue;
+      if (r == m) acc = have ? acc + v[m] : v[m], have = true;
+      if (m >= NQ && r == m - NQ) acc = have ? acc + h * v[m] : h * v[m], have = true;
+    }
+    y[r] = acc;
   }
 }
 
