@@ -437,8 +437,13 @@ class ClosedLoop:
                 continue
             st.wait_stream(cur)                      # whatever produced `state` on the caller's stream comes first
             old = s.state
+            _require_cuda_tensor(state, "state", self.dtype)
+            if tuple(part.shape) != tuple(old.shape):
+                raise ValueError("state must be [%d, %d]" % (old.shape[0], self.batch))
             with torch.cuda.stream(st):
-                s.set_state(part)                    # the clone is queued on, and belongs to the pool of, the range's stream
+                # the copy (contiguous: a column range of `state` is a strided view) is queued on, and belongs to the pool
+                # of, the range's stream
+                s.state = part.clone(memory_format=torch.contiguous_format)
             part.record_stream(st)                   # `state` is read there: its memory is not reused before that copy
             old.record_stream(st)                    # the plant of the last tick may still be reading the replaced tensor
         self._inputs_dirty = len(self.sims) > 1

@@ -51,6 +51,9 @@ def main():
     dtype = args[1] if len(args) > 1 else "f32"
     batch = int(args[2]) if len(args) > 2 else 262144
     N = 40
+    # --nx=6: the 6-state model's workload (tools/prof_workload.sh ... double): finalize reads x0 [6] and writes predicted [N][6];
+    # its traffic file is profiles/traffic_latest_double_<dtype>.json (bench.py variants.double_pendulum reads it)
+    nx = next((int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--nx=")), 4)
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     out_dir = os.path.join(ROOT, "profiles")
     os.makedirs(out_dir, exist_ok=True)
@@ -82,8 +85,8 @@ def main():
                     counters[k][c] = sum(vals) / len(vals)
     esz = 4 if dtype == "f32" else 8
     known_read = (N + 4) * esz * batch + 5 * 4 * batch      # finalize: u, x0 (R) + status/iters/ls (int) + f, cn
-    known_read = ((N + 4 + 2) * esz + 3 * 4) * batch
-    known_write = ((N + 4 * N + 2) * esz + 3 * 4) * batch
+    known_read = ((N + nx + 2) * esz + 3 * 4) * batch
+    known_write = ((N + nx * N + 2) * esz + 3 * 4) * batch
     summary = {"tag": tag, "dtype": dtype, "batch": batch, "kernel_trace": stats, "pmc_per_launch": counters,
                "units": "FETCH_SIZE/WRITE_SIZE in KiB as reported by rocprofv3; *_bytes fields are corrected bytes"}
     traffic = {}
@@ -147,6 +150,8 @@ def main():
         json.dump(summary, fh, indent=1, sort_keys=True)
     if traffic and "--no-traffic" not in sys.argv:   # the headline workload only: bench.py reads this file
         tname = "traffic_latest.json" if dtype == "f32" else "traffic_latest_%s.json" % dtype
+        if nx != 4:
+            tname = "traffic_latest_double_%s.json" % dtype
         with open(os.path.join(out_dir, tname), "w") as fh:
             json.dump({"tag": tag, "dtype": dtype, "batch": batch, "per_launch_bytes": traffic,
                        "instruction_mix_per_wave": mix,
