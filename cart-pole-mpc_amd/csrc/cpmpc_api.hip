@@ -368,7 +368,7 @@ extern "C" int cpmpc_dtype(const cpmpc_solver* s) { return s ? s->dtype : -1; }
 extern "C" int cpmpc_model(const cpmpc_solver* s) { return s ? s->model : -1; }
 extern "C" int cpmpc_refines_qp(const cpmpc_solver* s) { return s ? (s->refine_qp && s->dtype == CPMPC_F64 ? 1 : 0) : -1; }
 extern "C" int cpmpc_wide_qp(const cpmpc_solver* s) {
-  return s ? (s->wide_qp && use_fused(s) ? 1 : 0) : -1;
+  return s ? (s->wide_qp ? 1 : 0) : -1;  // either pipeline since round 6 (qp_ls_kernel<R, M, true>)
 }
 extern "C" int cpmpc_has_previous_solution(const cpmpc_solver* s) { return (s && s->prev_B > 0) ? 1 : 0; }
 extern "C" int64_t cpmpc_previous_solution_batch(const cpmpc_solver* s) { return s ? s->prev_B : 0; }

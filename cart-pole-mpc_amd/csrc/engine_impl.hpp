@@ -265,7 +265,10 @@ static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* 
       launch_linearize<R, M>(a, s->SP, a.zx, a.zu, a.ist, stream);
       span_end(s, stream, &sp);
       span_begin(s, CPMPC_KERNEL_QP_LS, stream, &sp);
-      hipLaunchKernelGGL((qp_ls_kernel<R, M>), gridB, dim3(64), 0, stream, a);
+      if (sizeof(R) == 4 && s->wide_qp)   // float handle with the QP's terminal part in double (CPMPC_CREATE_WIDE_QP)
+        hipLaunchKernelGGL((qp_ls_kernel<R, M, true>), gridB, dim3(64), 0, stream, a);
+      else
+        hipLaunchKernelGGL((qp_ls_kernel<R, M, false>), gridB, dim3(64), 0, stream, a);
       span_end(s, stream, &sp);
     }
   }

@@ -445,56 +445,6 @@ __device__ __forceinline__ void stage_chain_first_m(const R (&Ja)[NQ][NX], const
   }
 }
 
-// stage_chain_m fused with what its caller does with the result, ONE COLUMN AT A TIME and in place: column c of D_{j+1}
-// depends on column c of D_j only, so the new column lives in NX temporaries, is added to the running sum with weight W2
-// (As += 2 D_{j+1}; LAST: A = I + h/6 (As + D_4) instead) and replaces the old one -- a third NX x NX block (Dn) never exists.
-// Same operations in the same order per entry as stage_chain_m + the caller's loops.
-#ifndef CPMPC_RK4_CHAIN_INPLACE
-#define CPMPC_RK4_CHAIN_INPLACE 1   // models with known columns only (the 6-state one); 0: three blocks (A/B)
-#endif
-template <typename R, int NX, int NQ, unsigned ZMASK, bool LAST>
-__device__ __forceinline__ void stage_chain_inplace_m(const R (&Ja)[NQ][NX], const R (&Jua)[NQ], const R a, const R h6,
-                                                      R (&D)[NX][NX], R (&d)[NX], R (&As)[NX][NX], R (&bs)[NX],
-                                                      R (&A)[NX][NX], R (&Bv)[NX]) {
-  constexpr int k0 = first_nonzero_col<NX>(ZMASK);
-  constexpr unsigned TRIV = CPMPC_JA_TRIVIAL_COLS ? trivial_cols<NX, NQ>(ZMASK) : 0u;
-#pragma unroll
-  for (int c = 0; c <= NX; ++c) {   // c == NX: the control's column (d, bs, Bv)
-    if (c < NX && ((TRIV >> c) & 1u)) continue;
-    R col[NX], nw[NX];
-#pragma unroll
-    for (int r = 0; r < NX; ++r) col[r] = (c < NX) ? D[r][c < NX ? c : 0] : d[r];
-#pragma unroll
-    for (int r = 0; r < NQ; ++r) nw[r] = (c < NX) ? a * col[NQ + r] + (c == NQ + r ? R(1) : R(0)) : a * col[NQ + r];
-#pragma unroll
-    for (int r = 0; r < NQ; ++r) {
-      R acc = Ja[r][k0] * col[k0];
-#pragma unroll
-      for (int kk = k0 + 1; kk < NX; ++kk)
-        if (!((ZMASK >> kk) & 1u)) acc += Ja[r][kk] * col[kk];
-      if (c < NX) nw[NQ + r] = ((ZMASK >> (c < NX ? c : 0)) & 1u) ? a * acc : Ja[r][c < NX ? c : 0] + a * acc;
-      else nw[NQ + r] = a * acc + Jua[r];
-    }
-#pragma unroll
-    for (int r = 0; r < NX; ++r) {
-      if (c < NX) {
-        const int cc = c < NX ? c : 0;
-        if (LAST) A[r][cc] = (r == cc ? R(1) : R(0)) + h6 * (As[r][cc] + nw[r]);
-        else {
-          As[r][cc] += nw[r] * R(2);
-          D[r][cc] = nw[r];
-        }
-      } else {
-        if (LAST) Bv[r] = h6 * (bs[r] + nw[r]);
-        else {
-          bs[r] += nw[r] * R(2);
-          d[r] = nw[r];
-        }
-      }
-    }
-  }
-}
-
 #ifndef CPMPC_RK4_STAGE2_STRUCTURED
 #define CPMPC_RK4_STAGE2_STRUCTURED 1
 #endif
@@ -576,10 +526,6 @@ __device__ __forceinline__ void rk4_step_jac_m(const typename M::Consts& k, cons
     xt[NQ + i] = v3[i];
   }
   M::template accel_stage<true, HAS_EXT, 3>(k, xt, u, fe, a3, Ja, Jua, sc);
-  constexpr bool kInPlace = CPMPC_RK4_CHAIN_INPLACE && ZM != 0u;
-  if constexpr (kInPlace) {
-    stage_chain_inplace_m<R, NX, NQ, ZM, false>(Ja, Jua, hh, h / R(6), D, d, As, bs, A, Bv);
-  } else {
   stage_chain_m<R, NX, NQ, ZM>(Ja, Jua, hh, D, d, Dn, dn);
 #pragma unroll
   for (int r = 0; r < NX; ++r) {
@@ -592,7 +538,6 @@ __device__ __forceinline__ void rk4_step_jac_m(const typename M::Consts& k, cons
     bs[r] += dn[r] * R(2);
     d[r] = dn[r];
   }
-  }
 
   // stage 4
 #pragma unroll
@@ -603,14 +548,6 @@ __device__ __forceinline__ void rk4_step_jac_m(const typename M::Consts& k, cons
   }
   M::template accel_stage<true, HAS_EXT, 4>(k, xt, u, fe, a4, Ja, Jua, sc);
   const R h6 = h / R(6);
-  if constexpr (kInPlace) {
-    stage_chain_inplace_m<R, NX, NQ, ZM, true>(Ja, Jua, h, h6, D, d, As, bs, A, Bv);
-#pragma unroll
-    for (int r = 0; r < NX; ++r)
-#pragma unroll
-      for (int c = 0; c < NX; ++c)
-        if ((TRIV >> c) & 1u) A[r][c] = (r == c) ? R(1) : ((c >= NQ && r == c - NQ) ? h : R(0));  // e_c (+ h e_{c-NQ}): see trivial_cols
-  } else {
   stage_chain_m<R, NX, NQ, ZM>(Ja, Jua, h, D, d, Dn, dn);
 #pragma unroll
   for (int r = 0; r < NX; ++r) {
@@ -620,7 +557,6 @@ __device__ __forceinline__ void rk4_step_jac_m(const typename M::Consts& k, cons
       else A[r][c] = (r == c ? R(1) : R(0)) + h6 * (As[r][c] + Dn[r][c]);
     }
     Bv[r] = h6 * (bs[r] + dn[r]);
-  }
   }
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {

@@ -615,13 +615,22 @@ __device__ __forceinline__ void merit_eval(const SolverArgs<R, M>& a, const type
 // ------------------------------------------------------------------------------------------------
 // The terminal system (S, rho, the weighted free response, the LDL^T and its solve) is carried in the wide type W of
 // wide.hpp: double in a float kernel, R itself in a double kernel.
-template <typename R, typename M>
+// WIDEQ (float handles with CPMPC_CREATE_WIDE_QP, the default for the 6-state model; round 6): as in the fused kernel (type Q
+// of mpc_fused_body.inc), everything between the linearisation and the multipliers' effect on the step is carried in double
+// too -- the Psi products across the intervals, the columns w_k of U^-1 R^T, psi = Psi^T q and y = -(gw + W q).  W is then
+// never read back in float: after the multipliers are known a pass of its own ("sweep 1b", k descending) forms
+//     w_k . q = psi_s . Gamma_k - ups_k (w_{k+1} . q),   psi_s = Phi_{s+1}^T psi_{s+1},  psi_{S-2} = diag(w) q
+// in double and leaves y_k in the slot of (U^-1 g)_k.  One more pass over Gamma, Phi and T than the plain kernel: this
+// pipeline is the fall-back for shapes the fused kernel is not built for, correctness is its bar, not throughput.
+template <typename R, typename M, bool WIDEQ = false>
 __global__ CPMPC_QPLS_BOUNDS void qp_ls_kernel(const SolverArgs<R, M> a) {
   using V4 = typename VecT<R>::V4;
   using XVn = XV<R, M::NX>;
   using W = typename WideOf<R>::type;
   using WO = Wide<W>;
   constexpr bool kWidened = !std::is_same<W, R>::value;
+  constexpr bool kWideQP = WIDEQ && kWidened;
+  using Q = std::conditional_t<kWideQP, W, R>;
   constexpr int NX = M::NX;
   const unsigned p = blockIdx.x * 64u + threadIdx.x;
   if (p >= a.B) return;
@@ -690,16 +699,16 @@ __global__ CPMPC_QPLS_BOUNDS void qp_ls_kernel(const SolverArgs<R, M> a) {
   }
   bool pd_ok = true;
   {
-    R Psi[NX][NX];
+    Q Psi[NX][NX];
 #pragma unroll
     for (int r = 0; r < NX; ++r)
 #pragma unroll
-      for (int c = 0; c < NX; ++c) Psi[r][c] = (r == c) ? Rw[r] : R(0);
-    R wprev[NX];
+      for (int c = 0; c < NX; ++c) Psi[r][c] = (r == c) ? Q(Rw[r]) : Q(0);
+    Q wprev[NX];
     W ha[NX];
 #pragma unroll
     for (int r = 0; r < NX; ++r) {
-      wprev[r] = R(0);
+      wprev[r] = Q(0);
       ha[r] = WO::of(R(0));
     }
     R gwprev = R(0);
@@ -735,23 +744,28 @@ __global__ CPMPC_QPLS_BOUNDS void qp_ls_kernel(const SolverArgs<R, M> a) {
         const R inv_d = R(1) / dk;
         d_next = dk;
         // m_k = Psi Gamma_k ; w_k = m_k - ups w_{k+1}
-        R wk[NX];
+        Q wk[NX];
 #pragma unroll
         for (int r = 0; r < NX; ++r) {
-          R m = Psi[r][0] * gk[0];
+          Q m = Psi[r][0] * Q(gk[0]);
 #pragma unroll
-          for (int c = 1; c < NX; ++c) m += Psi[r][c] * gk[c];
-          wk[r] = m - ups * wprev[r];
+          for (int c = 1; c < NX; ++c) m += Psi[r][c] * Q(gk[c]);
+          wk[r] = m - Q(ups) * wprev[r];
         }
         const R gw = g - ups * gwprev;
-        a.Wk[(int64_t)kk * st + p] = pack<R, NX>(wk);
+        if constexpr (!kWideQP) {  // (the wide kernel never reads W back: sweep 1b below)
+          R wk_r[NX];
+#pragma unroll
+          for (int r = 0; r < NX; ++r) wk_r[r] = (R)wk[r];
+          a.Wk[(int64_t)kk * st + p] = pack<R, NX>(wk_r);
+        }
         a.Tk[(int64_t)kk * st + p] = mk4<R>(gw, ups, inv_d, g);
 #pragma unroll
         for (int i2 = 0; i2 < NX; ++i2) {
-          const W wi = WO::prod(wk[i2], inv_d);  // exact in W: S is the Gram matrix of the rounded rows (wide.hpp)
+          const W wi = (W)wk[i2] * (W)inv_d;  // exact in W for float columns: S is the Gram matrix of the rounded rows (wide.hpp)
           rho[i2] += wi * gw;
 #pragma unroll
-          for (int j2 = 0; j2 <= i2; ++j2) Sm[i2][j2] += wi * wk[j2];
+          for (int j2 = 0; j2 <= i2; ++j2) Sm[i2][j2] += wi * (W)wk[j2];
         }
 #pragma unroll
         for (int r = 0; r < NX; ++r) wprev[r] = wk[r];
@@ -767,23 +781,24 @@ __global__ CPMPC_QPLS_BOUNDS void qp_ls_kernel(const SolverArgs<R, M> a) {
         for (int t = 0; t < NX; ++t) cn += Math<R>::fabs(c[t]);
 #pragma unroll
         for (int r = 0; r < NX; ++r) {
-          W acc = WO::prod(Psi[r][0], c[0]);
+          W acc = (W)Psi[r][0] * (W)c[0];
 #pragma unroll
-          for (int m = 1; m < NX; ++m) acc += WO::prod(Psi[r][m], c[m]);
+          for (int m = 1; m < NX; ++m) acc += (W)Psi[r][m] * (W)c[m];
           ha[r] += acc;
         }
       }
       // Psi <- Psi Phi_s
-      R Ph[NX][NX], T[NX][NX];
+      R Ph[NX][NX];
+      Q T[NX][NX];
 #pragma unroll
       for (int r = 0; r < NX; ++r) unpack<R, NX>(a.Phi[(int64_t)(NX * s + r) * st + p], Ph[r]);
 #pragma unroll
       for (int r = 0; r < NX; ++r)
 #pragma unroll
         for (int c = 0; c < NX; ++c) {
-          R acc = Psi[r][0] * Ph[0][c];
+          Q acc = Psi[r][0] * Q(Ph[0][c]);
 #pragma unroll
-          for (int m = 1; m < NX; ++m) acc += Psi[r][m] * Ph[m][c];
+          for (int m = 1; m < NX; ++m) acc += Psi[r][m] * Q(Ph[m][c]);
           T[r][c] = acc;
         }
 #pragma unroll
@@ -794,9 +809,9 @@ __global__ CPMPC_QPLS_BOUNDS void qp_ls_kernel(const SolverArgs<R, M> a) {
     // Psi is now diag(w) Phi_{S-2}...Phi_0: contribution of dx_0 = -c_init
 #pragma unroll
     for (int r = 0; r < NX; ++r) {
-      W acc = WO::prod(Psi[r][0], ci[0]);
+      W acc = (W)Psi[r][0] * (W)ci[0];
 #pragma unroll
-      for (int m = 1; m < NX; ++m) acc += WO::prod(Psi[r][m], ci[m]);
+      for (int m = 1; m < NX; ++m) acc += (W)Psi[r][m] * (W)ci[m];
       hv[r] += ha[r] - acc;
     }
   }
@@ -806,7 +821,7 @@ __global__ CPMPC_QPLS_BOUNDS void qp_ls_kernel(const SolverArgs<R, M> a) {
   if (!Math<R>::finite(f) || !Math<R>::finite(cn)) status = kTermNonFinite;
 
   // ---- (S + Dg) q = h - rho by LDL^T on the lower triangle, in registers ------------------------
-  R q[NX];
+  Q q[NX];
   W Lm[NX][NX], dv[NX], idv[NX];  // (function scope: the refinement after sweep 2 solves with them again)
   {
 #pragma unroll
@@ -854,7 +869,7 @@ __global__ CPMPC_QPLS_BOUNDS void qp_ls_kernel(const SolverArgs<R, M> a) {
     for (int i = 0; i < NX; ++i) rhs[i] = hv[i] - rho[i];
     ldl_solve(rhs, qw);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) q[i] = (R)qw[i];
+    for (int i = 0; i < NX; ++i) q[i] = (Q)qw[i];
     // One step of iterative refinement of q with the residual taken through the factored operator
     // (S = W^T D^-1 W is a normal-equations matrix; see mpc_fused_body.inc).  fp64 only HERE: this kernel is bound by
     // its workspace traffic and the pass re-reads W and T from HBM (+25 % bytes); the fused kernel, where the pass is
@@ -885,6 +900,41 @@ __global__ CPMPC_QPLS_BOUNDS void qp_ls_kernel(const SolverArgs<R, M> a) {
   }
   if (status == kTermNone && !pd_ok) status = kTermQpIndefinite;
 
+  // ---- sweep 1b (wide QP only; k descending): y_k = -(gw_k + w_k . q) in double, left in the slot of gw_k -------------
+  if constexpr (kWideQP) {
+    Q psi[NX];
+#pragma unroll
+    for (int c = 0; c < NX; ++c) psi[c] = Q(Rw[c]) * q[c];  // Psi_{S-2}^T q, Psi_{S-2} = diag(w)
+    Q om = Q(0);
+    int kk = N - 1;
+    for (int s = S - 2; s >= 0; --s) {
+      for (int i = SP - 1; i >= 0; --i, --kk) {
+        R gk[NX];
+        unpack<R, NX>(a.Gam[(int64_t)kk * st + p], gk);
+        V4 T = a.Tk[(int64_t)kk * st + p];
+        Q pg = psi[0] * Q(gk[0]);
+#pragma unroll
+        for (int m = 1; m < NX; ++m) pg += psi[m] * Q(gk[m]);
+        om = pg - Q(T.y) * om;                 // w_k . q
+        T.x = (R)(-(Q(T.x) + om));             // y_k
+        a.Tk[(int64_t)kk * st + p] = T;
+      }
+      // psi <- Phi_s^T psi for the interval below
+      Q pn[NX];
+#pragma unroll
+      for (int c = 0; c < NX; ++c) pn[c] = Q(0);
+#pragma unroll
+      for (int r = 0; r < NX; ++r) {
+        R row[NX];
+        unpack<R, NX>(a.Phi[(int64_t)(NX * s + r) * st + p], row);
+#pragma unroll
+        for (int c = 0; c < NX; ++c) pn[c] += Q(row[c]) * psi[r];
+      }
+#pragma unroll
+      for (int c = 0; c < NX; ++c) psi[c] = pn[c];
+    }
+  }
+
   // ---- sweep 2 (k ascending): U^T du = D^-1 y, state recovery, directional quantities -----------
   R gd = R(0), curv = R(0);
   R dz_inf = R(0);  // |dz|_inf, for the full-step rule of the line search (nan_max drops a NaN component: see above)
@@ -901,7 +951,8 @@ __global__ CPMPC_QPLS_BOUNDS void qp_ls_kernel(const SolverArgs<R, M> a) {
     const XVn* __restrict__ w_p = a.Wk + p;
     const V4* __restrict__ t_p = a.Tk + p;
     const XVn* __restrict__ g_p = a.Gam + p;
-    XVn W_nx = w_p[0], G_nx = g_p[0];  // software pipeline, one column ahead
+    XVn W_nx, G_nx = g_p[0];  // software pipeline, one column ahead
+    if constexpr (!kWideQP) W_nx = w_p[0];
     V4 T_nx = t_p[0];
     int kk = 0;
     for (int s = 0; s + 1 < S; ++s) {
@@ -915,19 +966,25 @@ __global__ CPMPC_QPLS_BOUNDS void qp_ls_kernel(const SolverArgs<R, M> a) {
         for (int m = 0; m < NX; ++m) acc[r] += row[m] * dx[m];
       }
       for (int i = 0; i < SP; ++i, ++kk) {
-        R W[NX], G[NX];
-        unpack<R, NX>(W_nx, W);
+        R G[NX];
         unpack<R, NX>(G_nx, G);
         const V4 T = T_nx;
+        R y;
+        if constexpr (kWideQP) {
+          y = T.x;  // sweep 1b left y_k here
+        } else {
+          R Wr[NX];
+          unpack<R, NX>(W_nx, Wr);
+          R wq = Wr[0] * (R)q[0];
+#pragma unroll
+          for (int m = 1; m < NX; ++m) wq += Wr[m] * (R)q[m];
+          y = -(T.x + wq);
+        }
         if (kk + 1 < N) {
-          W_nx = w_p[(int64_t)(kk + 1) * st];
+          if constexpr (!kWideQP) W_nx = w_p[(int64_t)(kk + 1) * st];
           T_nx = t_p[(int64_t)(kk + 1) * st];
           G_nx = g_p[(int64_t)(kk + 1) * st];
         }
-        R wq = W[0] * q[0];
-#pragma unroll
-        for (int m = 1; m < NX; ++m) wq += W[m] * q[m];
-        const R y = -(T.x + wq);
         const R du = y * T.z - ups_prev * du_prev;
         a.dzu[(int64_t)kk * st + p] = du;
         dz_inf = nan_max(dz_inf, Math<R>::fabs(du));

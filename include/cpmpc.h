@@ -206,8 +206,10 @@ int cpmpc_refines_qp(const cpmpc_solver* s); /* 1: this handle's kernels refine 
  *                                for 0 - 5 % (51.0 -> 50.8 M near upright, 50.9 -> 48.3 M from within 0.5 rad).
  * DEFAULT (neither flag): ON for the 6-state model -- without it four of five float solves of that model are off by more
  * than 0.01 N after five iterations -- and OFF for the 4-state one (the reference's model: speed first, the bar of this
- * path is met by CPMPC_F64 handles).  The fused pipeline only (every spacing it serves; the split pipeline keeps the
- * round-4 arithmetic).  cpmpc_wide_qp() tells what a handle does. */
+ * path is met by CPMPC_F64 handles).  Both pipelines since round 6: a float handle that AUTO or cpmpc_set_pipeline() sends to
+ * the split pipeline (state spacings the fused kernel is not built for) runs qp_ls_kernel's wide form -- the same quantities
+ * in double, one more pass over the workspace -- and lands where the fused one does (tests/test_gpu_round6.py: the 6-state
+ * model at state_spacing 20 against the float CPU check).  cpmpc_wide_qp() tells what a handle does, in either pipeline. */
 int cpmpc_wide_qp(const cpmpc_solver* s);
 /* seconds: the longest horizon held to 1e-5 of the CPU check on every problem (1.0) */
 double cpmpc_max_parity_horizon(void);
