@@ -151,11 +151,16 @@ def free_port():
 
 def launch_ranks(n, argv, n_devices=None, script=None, timeout=None):
     """Start n fresh rank processes (never a re-exec of a process that has touched the GPU), wait for them and return
-    (exit code, rank 0's stdout).  Rank 0's stdout is captured (read on a thread, so a full pipe never blocks it), the
-    other ranks write to stderr.  All ranks are polled together: the first one to exit non-zero ends the run at once --
-    the others (which would otherwise sit in a collective until its timeout) are killed and that exit code is returned.
-    `timeout` (default CPMPC_BENCH_TIMEOUT or 3600 s) bounds the whole run the same way.  Never restarts anything."""
-    import tempfile
+    (exit code, rank 0's stdout).  Rank 0's stdout is captured (read on a thread, so a full pipe never blocks it).  Every
+    rank's stderr (and the stdout of ranks > 0) is TEED: a reader thread per rank forwards each line to this process's stderr
+    as it arrives, prefixed "[rank r] " -- the device report, warnings and an RCCL error reach the log even if the driver
+    kills the launcher before the run ends -- and keeps the last 40 lines, which are printed once more under the
+    launcher's verdict when a rank fails (on an 8-GPU node the first contact with RCCL fails in one rank, and its message
+    must not be lost among seven others').  All ranks are polled together: the first one to exit non-zero ends
+    the run at once -- the others (which would otherwise sit in a collective until its timeout) are killed and that exit
+    code is returned.  `timeout` (default CPMPC_BENCH_TIMEOUT or 3600 s) bounds the whole run the same way.  Never restarts
+    anything."""
+    import collections
     import threading
     share = os.environ.get("CPMPC_BENCH_SHARE_DEVICE", "0") == "1"
     if n_devices is None:
@@ -166,19 +171,36 @@ def launch_ranks(n, argv, n_devices=None, script=None, timeout=None):
     cmd = [sys.executable, script or os.path.abspath(__file__)] + list(argv)
     procs = []
     chunks = []
-    reader = None
+    readers = []
+    tails = [collections.deque(maxlen=40) for _ in range(n)]
+    out_lock = threading.Lock()
     rc = 0
     failed_rank = None
-    # every rank's stderr (and the stdout of ranks > 0) goes to a file of its own: relayed to this process's stderr when the
-    # run ends, and on a failure the failing rank's LAST 40 LINES are printed under the launcher's verdict -- on an 8-GPU
-    # node the first contact with RCCL fails in one rank, and its message must not be lost among seven others' 
-    logdir = tempfile.mkdtemp(prefix="cpmpc_bench_ranks_")
-    logs = [open(os.path.join(logdir, "rank%d.stderr" % r), "w+") for r in range(n)]
+
+    def tee(r, stream):
+        for ln in iter(stream.readline, ""):
+            ln = ln.rstrip("\n")
+            tails[r].append(ln)
+            with out_lock:
+                sys.stderr.write("[rank %d] %s\n" % (r, ln))
+                sys.stderr.flush()
+        stream.close()
+
     try:
         for r, e in enumerate(envs):
-            procs.append(subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if r == 0 else logs[r], stderr=logs[r], text=True))
-        reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
-        reader.start()
+            # rank 0: stdout is the result (captured), stderr is teed; ranks > 0: stdout and stderr both go to the tee
+            p = subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE if r == 0 else subprocess.STDOUT,
+                                 text=True, bufsize=1)
+            procs.append(p)
+            if r == 0:
+                t0 = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+                t0.start()
+                readers.append(t0)
+                t = threading.Thread(target=tee, args=(0, p.stderr), daemon=True)
+            else:
+                t = threading.Thread(target=tee, args=(r, p.stdout), daemon=True)
+            t.start()
+            readers.append(t)
         deadline = time.monotonic() + timeout
         while True:
             codes = [p.poll() for p in procs]
@@ -186,13 +208,15 @@ def launch_ranks(n, argv, n_devices=None, script=None, timeout=None):
             if bad:
                 rc = bad[0]
                 failed_rank = codes.index(bad[0])
-                sys.stderr.write("bench.py launcher: rank %d exited with code %d; stopping the other ranks\n" % (failed_rank, bad[0]))
+                with out_lock:
+                    sys.stderr.write("bench.py launcher: rank %d exited with code %d; stopping the other ranks\n" % (failed_rank, bad[0]))
                 break
             if all(c == 0 for c in codes):
                 break
             if time.monotonic() > deadline:
                 rc = 124
-                sys.stderr.write("bench.py launcher: no result after %.0f s; stopping the ranks\n" % timeout)
+                with out_lock:
+                    sys.stderr.write("bench.py launcher: no result after %.0f s; stopping the ranks\n" % timeout)
                 break
             time.sleep(0.05)
     finally:
@@ -204,33 +228,16 @@ def launch_ranks(n, argv, n_devices=None, script=None, timeout=None):
                 p.wait(timeout=30)
             except subprocess.TimeoutExpired:
                 pass
-        if reader is not None:
-            reader.join(timeout=30)
-        texts = []
-        for r, fh in enumerate(logs):
-            try:
-                fh.flush()
-                fh.seek(0)
-                texts.append(fh.read())
-            except (OSError, ValueError):
-                texts.append("")
-            fh.close()
-        for r, t in enumerate(texts):   # the ranks' own messages (device report, warnings, RCCL banner), rank by rank
-            for ln in t.splitlines():
-                sys.stderr.write("[rank %d] %s\n" % (r, ln))
+        for t in readers:
+            t.join(timeout=30)
         if failed_rank is not None or rc == 124:
-            which = [failed_rank] if failed_rank is not None else list(range(n))
+            which = [failed_rank] if failed_rank is not None else list(range(len(procs)))
             for r in which:
-                tail = texts[r].splitlines()[-40:] if r < len(texts) else []
+                tail = list(tails[r])
                 sys.stderr.write("bench.py launcher: last %d stderr line(s) of rank %d:\n" % (len(tail), r))
                 for ln in tail:
                     sys.stderr.write("    | %s\n" % ln)
-        try:
-            for r in range(n):
-                os.remove(os.path.join(logdir, "rank%d.stderr" % r))
-            os.rmdir(logdir)
-        except OSError:
-            pass
+        sys.stderr.flush()
     return rc, "".join(c for c in chunks if c)
 
 
@@ -699,7 +706,7 @@ def wide_qp_variant(torch, pkg, args, dev, local_rank, B, lanes=8192, steps=20):
     u_c, _, st_c, _, _ = orc.step_batch_cold(orc.default_opt_params(**over), DYN_UI, 0.0, x_np[:, idx])
     res = {"note": "fp32, B = %d, cold start, %d iterations, exits disabled; parity = max |du| per problem against the double CPU "
                    "check on %d evenly spaced lanes" % (B, args.iters, idx.size)}
-    for name, wide in (("default", False), ("wide_qp", True)):
+    for name, wide in (("default", None), ("wide_qp", True)):
         quiesce(torch)
         opt = pkg.BatchOptimization(pkg.default_params(**over), max_batch=B, dtype=torch.float32, device=local_rank, wide_qp=wide)
         opt.set_pipeline(args.pipeline)
@@ -1115,11 +1122,12 @@ def run_rank(args):
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "preheated": args.preheat_seconds > 0.0, "preheat_s": args.preheat_seconds, "preheat_steps": n_pre,
         "config": {"workload": "BASELINE configs[%d]%s: batch=%d per GPU (%d in total), N=40, state_spacing=10, %s, cold start, "
-                               "%d SQP iterations (exits disabled), u+predicted+status written%s"
+                               "%d SQP iterations (exits disabled), u+predicted+status written%s%s"
                                % (2 if shard_world == 1 else 3,
                                   " -- the shard of rank %d of %d, solved alone on this GPU" % (shard_rank, shard_world)
                                   if as_rank else "", B, total, args.dtype, args.iters,
-                                  ", u gathered to rank 0 (%s)" % ("RCCL" if backend == "nccl" else "gloo") if gather else ""),
+                                  ", u gathered to rank 0 (%s)" % ("RCCL" if backend == "nccl" else "gloo") if gather else "",
+                                  ", QP terminal part in double" if (args.dtype == "f32" and opt.wide_qp) else ""),
                    "batch_per_gpu": B, "global_batch": total, "horizon": N, "sqp_iterations": args.iters,
                    "pipeline": opt.pipeline(), "parallelism": "dp%d" % world},
         "roofline": roofline_of(prof, args.dtype, B, args.iters, args.steps, value / world),

@@ -48,11 +48,15 @@ class BatchOutputs:
         self.final_cost = None        # [B]
         self.final_eq_l1 = None       # [B]
         self.guess = None             # [dim, B]
+        self.horizon_beyond_parity = False   # cpmpc_horizon_beyond_parity() of the handle that filled these outputs
 
     def solver_summary(self):
         """Batch summary in the spirit of NLSSolverOutputs::ToString (wrapper/wrapper.cc:82-83)."""
         st = self.status.cpu()
         lines = ["batch of %d problems" % st.numel()]
+        if getattr(self, "horizon_beyond_parity", False):
+            lines.append("  horizon beyond %.1f s (cpmpc_max_parity_horizon): a few cold starts in 10^4 may differ from a "
+                         "full-space solve by more than 1e-5" % capi.load().cpmpc_max_parity_horizon())
         for code in sorted(set(st.tolist())):
             lines.append("  %-28s %d" % (capi.TERM_NAMES.get(code, str(code)), int((st == code).sum())))
         if self.iterations is not None:
@@ -218,6 +222,7 @@ class BatchOptimization:
         with torch.cuda.device(self.device):
             capi.check(lib.cpmpc_step_batch(self._h, B, C.byref(inp), C.byref(outp), _stream_ptr()))
         self._keep = keep  # inputs must outlive the asynchronous launch
+        o.horizon_beyond_parity = self.horizon_beyond_parity
         return o
 
     # -- Optimization::Reset / SetPreviousSolution ---------------------------------------------
@@ -268,11 +273,17 @@ class BatchOptimization:
         capi.check(capi.load().cpmpc_set_pipeline(self._h, capi.PIPELINES[mode]))
 
     @property
+    def horizon_beyond_parity(self):
+        """True: window_length * control_dt exceeds cpmpc_max_parity_horizon() (include/cpmpc.h: cpmpc_horizon_beyond_parity)."""
+        return bool(capi.load().cpmpc_horizon_beyond_parity(self._h))
+
+    @property
     def refines_qp(self):
         return bool(capi.load().cpmpc_refines_qp(self._h))
 
     @property
     def wide_qp(self):
+        """True: this float handle's steps carry the QP's terminal part in double (include/cpmpc.h: CPMPC_CREATE_WIDE_QP)."""
         return bool(capi.load().cpmpc_wide_qp(self._h))
 
     def set_compaction(self, first_iterations=2, next_iterations=1):

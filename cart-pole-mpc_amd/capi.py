@@ -29,7 +29,7 @@ PIPELINES = {"auto": 0, "split": 1, "fused": 2, 0: 0, 1: 1, 2: 2}
 # every symbol include/cpmpc.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "cpmpc_default_params", "cpmpc_default_solver_opts", "cpmpc_last_error", "cpmpc_device_count",
-    "cpmpc_create", "cpmpc_create_ex", "cpmpc_max_parity_horizon", "cpmpc_refines_qp", "cpmpc_wide_qp", "cpmpc_destroy", "cpmpc_supported_state_spacing", "cpmpc_step_batch",
+    "cpmpc_create", "cpmpc_create_ex", "cpmpc_max_parity_horizon", "cpmpc_horizon_beyond_parity", "cpmpc_get_solver_opts", "cpmpc_refines_qp", "cpmpc_wide_qp", "cpmpc_destroy", "cpmpc_supported_state_spacing", "cpmpc_step_batch",
     "cpmpc_reset", "cpmpc_set_previous_solution", "cpmpc_get_solution",
     "cpmpc_has_previous_solution", "cpmpc_previous_solution_batch", "cpmpc_dim", "cpmpc_num_states", "cpmpc_dtype",
     "cpmpc_step_batch_host", "cpmpc_step_batch_host_ex", "cpmpc_set_previous_solution_host", "cpmpc_get_solution_host",
@@ -204,6 +204,10 @@ def load():
     L.cpmpc_create_ex.argtypes = [C.POINTER(CreateInfo), C.POINTER(vp)]
     L.cpmpc_wide_qp.argtypes = [vp]
     L.cpmpc_wide_qp.restype = i32
+    L.cpmpc_get_solver_opts.argtypes = [vp, C.POINTER(SolverOpts), C.c_size_t]
+    L.cpmpc_get_solver_opts.restype = i32
+    L.cpmpc_horizon_beyond_parity.argtypes = [vp]
+    L.cpmpc_horizon_beyond_parity.restype = i32
     L.cpmpc_refines_qp.argtypes = [vp]
     L.cpmpc_max_parity_horizon.argtypes = []
     L.cpmpc_max_parity_horizon.restype = dbl

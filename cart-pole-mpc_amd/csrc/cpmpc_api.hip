@@ -181,11 +181,13 @@ static int create_impl(const cpmpc_params* params, const cpmpc_solver_opts* opts
     return fail(CPMPC_ERR_INVALID_ARG, "CPMPC_CREATE_REFINE_QP and CPMPC_CREATE_NO_REFINE_QP exclude each other");
   if ((flags & CPMPC_CREATE_WIDE_QP) && (flags & CPMPC_CREATE_NO_WIDE_QP))
     return fail(CPMPC_ERR_INVALID_ARG, "CPMPC_CREATE_WIDE_QP and CPMPC_CREATE_NO_WIDE_QP exclude each other");
-  // the struct in some release: the leading int (padded to 8) and a whole number of doubles, from the first release's 13
-  // (104 bytes) to this one's; a size that splits a field is nobody's struct
-  if (opts != nullptr && (opts_size < 104 || opts_size > sizeof(cpmpc_solver_opts) || opts_size % 8 != 0))
+  // the struct in some release: the leading int (padded to 8) and a whole number of doubles, from the shortest layout that is
+  // a PREFIX of today's struct -- 13 doubles, through u_limit: 112 bytes -- to this one's.  (The 104-byte struct of the very
+  // first commit had no ls_alpha_growth, which was inserted mid-struct before any release: read as today's prefix it would
+  // shift every later field by one slot, so it is refused, like a size that splits a field: ADVICE r4, r5.)
+  if (opts != nullptr && (opts_size < 112 || opts_size > sizeof(cpmpc_solver_opts) || opts_size % 8 != 0))
     return fail(CPMPC_ERR_INVALID_ARG, "opts_size %zu is not the size of any cpmpc_solver_opts this library knows (8 + 8 k "
-                "bytes, 104 .. %zu)", opts_size, sizeof(cpmpc_solver_opts));
+                "bytes, 112 .. %zu)", opts_size, sizeof(cpmpc_solver_opts));
   {
     // Every horizon the reference's constructor accepts is accepted (optimization.cc:13-22: this is a drop-in); beyond
     // cpmpc_max_parity_horizon() the first handle of the process says so once, and CPMPC_CREATE_STRICT_HORIZON refuses.
@@ -223,9 +225,18 @@ static int create_impl(const cpmpc_params* params, const cpmpc_solver_opts* opts
   s->params = *params;
   s->opts = merged;
   s->dtype = dtype;
-  // default: refine where the control cost is weak (measured: include/cpmpc.h, CPMPC_CREATE_REFINE_QP)
+  s->beyond_parity = (double)params->window_length * params->control_dt > kMaxParityHorizon * (1.0 + 1e-9);
+  // default: refine where the control cost is weak (measured: include/cpmpc.h, CPMPC_CREATE_REFINE_QP) and, since round 6,
+  // beyond the parity horizon: there one pass of refinement with residuals from the original data takes the lanes on
+  // which the kernels (not the CPU check) moved from 34 of 8 192 to 3 at N = 160 (profiles/r06_long_horizon_probe.json);
+  // further passes change nothing (the refined solve and a dense pivoted one are then both at the problem's conditioning)
   s->refine_qp = (flags & CPMPC_CREATE_REFINE_QP) != 0 ||
-                 (!(flags & CPMPC_CREATE_NO_REFINE_QP) && params->u_cost_weight < kRefineBelowUCostWeight);
+                 (!(flags & CPMPC_CREATE_NO_REFINE_QP) && (params->u_cost_weight < kRefineBelowUCostWeight || s->beyond_parity));
+  s->refine_passes = 1;
+  if (const char* e = getenv("CPMPC_QP_REFINE_PASSES")) {   // diagnostic (tools/long_horizon_gpu_probe.py): passes of the split pipeline
+    const int n = atoi(e);
+    if (n >= 1 && n <= 16) s->refine_passes = n;
+  }
   // default: on for the 6-state model (measured: include/cpmpc.h, CPMPC_CREATE_WIDE_QP), off for the 4-state one
   s->wide_qp = dtype == CPMPC_F32 && ((flags & CPMPC_CREATE_WIDE_QP) != 0 ||
                                       (!(flags & CPMPC_CREATE_NO_WIDE_QP) && model == CPMPC_MODEL_DOUBLE));
@@ -367,6 +378,16 @@ extern "C" int cpmpc_num_states(const cpmpc_solver* s) { return s ? s->S : -1; }
 extern "C" int cpmpc_dtype(const cpmpc_solver* s) { return s ? s->dtype : -1; }
 extern "C" int cpmpc_model(const cpmpc_solver* s) { return s ? s->model : -1; }
 extern "C" int cpmpc_refines_qp(const cpmpc_solver* s) { return s ? (s->refine_qp && s->dtype == CPMPC_F64 ? 1 : 0) : -1; }
+// what a handle actually uses: defaults merged with as much of the caller's struct as its constructor read (the
+// positional constructors read 128 bytes, so a later field -- exit_defect_floor -- set through them is NOT taken)
+extern "C" int cpmpc_get_solver_opts(const cpmpc_solver* s, cpmpc_solver_opts* out, size_t out_size) {
+  if (!s || !out) return fail(CPMPC_ERR_INVALID_ARG, "null argument");
+  if (out_size < 112 || out_size > sizeof(cpmpc_solver_opts) || out_size % 8 != 0)
+    return fail(CPMPC_ERR_INVALID_ARG, "out_size %zu is not the size of any cpmpc_solver_opts this library knows", out_size);
+  memcpy(out, &s->opts, out_size);
+  return CPMPC_OK;
+}
+extern "C" int cpmpc_horizon_beyond_parity(const cpmpc_solver* s) { return s ? (s->beyond_parity ? 1 : 0) : -1; }
 extern "C" int cpmpc_wide_qp(const cpmpc_solver* s) {
   return s ? (s->wide_qp ? 1 : 0) : -1;  // either pipeline since round 6 (qp_ls_kernel<R, M, true>)
 }

@@ -93,6 +93,8 @@ struct cpmpc_solver {
   int64_t prof_n[CPMPC_KERNEL_COUNT] = {0, 0, 0, 0, 0};
   int pipeline = CPMPC_PIPELINE_AUTO;
   bool refine_qp = false;  // CPMPC_CREATE_REFINE_QP: the double fused kernels refine the whole QP solution once
+  bool beyond_parity = false;  // window_length * control_dt > cpmpc_max_parity_horizon(): cpmpc_horizon_beyond_parity()
+  int refine_passes = 0;   // split pipeline, double: passes of that refinement (1; 3 beyond the parity horizon: cpmpc_api.hip)
   bool wide_qp = false;    // CPMPC_CREATE_WIDE_QP (default for the 6-state model): the float fused kernels (compiled spacings) carry the QP's terminal part in double
   // staged fused pipeline (compaction of the still-active problems between stages); 0/0 = single launch
   // default 2 / 1 (round 4, tools/steady_state.py): in the warm-started closed loop most problems stop after one or two
@@ -147,7 +149,7 @@ static inline bool fused_built(const cpmpc_solver* s) { return fused_static(s->S
 static inline size_t fused_wave_lds_bytes(const cpmpc_solver* s) {
   const size_t col = (size_t)s->NX * s->esize;
   const size_t g_bytes = col % 16 == 0 ? col : (col + 7) / 8 * 8;
-  // (the slim layout is the double 6-state kernel's: mpc_fused.hpp, CPMPC_FUSED_SLIM_F64_NX6 = 1, ..._F32_NX6 = 0)
+  // (the slim layout is the double 6-state kernel's: mpc_fused.hpp, CPMPC_FUSED_SLIM_F64_NX6 = 1)
   const bool slim = s->esize == 8 && s->NX > 4 && !s->refine_qp && s->SP <= 10 && fused_static(s->S - 1, s->SP);
   return (size_t)s->SP * 64 * ((slim ? 2 : 4) * (size_t)s->esize + g_bytes);
 }

@@ -78,7 +78,7 @@ static void fill_args(const cpmpc_solver* s, int64_t B, SolverArgs<R, M>& a, int
   // problems [col0, col0 + B) of the workspace: every field is [field][cap] with the problem index fastest, so the call
   // works on a column range by offsetting the field bases (a chunk of a pipelined host-pointer step)
   a.prev_B = s->prev_B - col0 < 0 ? 0 : (s->prev_B - col0 > B ? B : s->prev_B - col0);
-  a.refine_qp = s->refine_qp ? 1 : 0;
+  a.refine_qp = s->refine_qp ? s->refine_passes : 0;
   using V4 = typename VecT<R>::V4;
   using XVn = XV<R, M::NX>;
   a.zx = (XVn*)s->zx + col0;
@@ -213,6 +213,12 @@ static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* 
   }
   const dim3 gridB = grid_for(B);
   ProfSpan sp;
+  // float handles: the QP with its terminal part in double (CPMPC_CREATE_WIDE_QP).  A property of the HANDLE, never of the step:
+  // round 6 tried "wide on cold-start steps only" as the 4-state default and withdrew it -- whether a call is a cold start
+  // depends on which problems share the call, so a sharded handle (whose last shard may be all cold) and a single one (partly
+  // warm) then ran different kernels on the same problem and batch-position independence was gone
+  // (test_sharded_device_step_takes_per_problem_inputs...: bitwise equality across shardings)
+  const bool wide_step = s->wide_qp;
 
   // (the first compaction's counter: cleared by prepare_kernel whether or not this step turns out to be staged)
   a.stage_count0 = (use_fused(s) && s->active != nullptr) ? s->active + s->cap + 3 * slot : nullptr;
@@ -237,7 +243,7 @@ static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* 
     a.iter_cap = total;
     a.run_out_below = (int64_t)2048 * (64 / (s->S - 1));  // problems in one round of resident waves (2 per SIMD)
     span_begin(s, CPMPC_KERNEL_FUSED, stream, &sp);
-    launch_fused<R, M>(a, s->S - 1, s->SP, bounds[1], sizeof(R) == 8 ? s->refine_qp : s->wide_qp, stream);
+    launch_fused<R, M>(a, s->S - 1, s->SP, bounds[1], sizeof(R) == 8 ? s->refine_qp : wide_step, stream);
     span_end(s, stream, &sp);
     for (int stage = 0; stage + 1 < n_stages; ++stage) {
       const int done = bounds[stage + 1];
@@ -256,7 +262,7 @@ static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* 
       a.active_list = s->active + col0;
       a.active_count = count;
       const int k = bounds[stage + 2] - done;
-      launch_fused<R, M>(a, s->S - 1, s->SP, k, sizeof(R) == 8 ? s->refine_qp : s->wide_qp, stream);
+      launch_fused<R, M>(a, s->S - 1, s->SP, k, sizeof(R) == 8 ? s->refine_qp : wide_step, stream);
       span_end(s, stream, &sp);
     }
   } else {
@@ -265,7 +271,7 @@ static int step_batch_impl(cpmpc_solver* s, int64_t B, const cpmpc_step_inputs* 
       launch_linearize<R, M>(a, s->SP, a.zx, a.zu, a.ist, stream);
       span_end(s, stream, &sp);
       span_begin(s, CPMPC_KERNEL_QP_LS, stream, &sp);
-      if (sizeof(R) == 4 && s->wide_qp)   // float handle with the QP's terminal part in double (CPMPC_CREATE_WIDE_QP)
+      if (sizeof(R) == 4 && wide_step)   // float handle with the QP's terminal part in double (CPMPC_CREATE_WIDE_QP)
         hipLaunchKernelGGL((qp_ls_kernel<R, M, true>), gridB, dim3(64), 0, stream, a);
       else
         hipLaunchKernelGGL((qp_ls_kernel<R, M, false>), gridB, dim3(64), 0, stream, a);

@@ -62,36 +62,98 @@ struct SingleModelHandWritten {
   }
 };
 
-// models without anything to share between the stages of a step
-struct NoStepCache {
-  __device__ __forceinline__ void invalidate() {}
-};
 // the same model on the generated code (README.md:60-71 "Changing the dynamics": edit the Lagrangian in
-// tools/gen_dynamics.py, run it, rebuild with -DCPMPC_GENERATED_SINGLE=1)
+// tools/gen_dynamics.py, run it, rebuild with -DCPMPC_GENERATED_SINGLE=1).  Round 6: generated in the form the 6-state model
+// has -- M(q) q'' = F terms with folded constants, sine / cosine and the helper terms as inputs, a hand-written 2 x 2 solve --
+// so that it shares the hand-written model's instruction diet: the RK4 stages rotate the pole's sine / cosine from stage 1's
+// pair (StepCache = TrigBase), the first pivot of the mass matrix and its reciprocal are parameters, one reciprocal per stage.
+template <typename R>
+struct SingleGenConsts {
+  SinglePendulumMFConsts<R> g;
+  R inv_m00;  // 1 / (m_b + m_1)
+};
 template <typename R>
 struct SingleModelGenerated {
   static constexpr int NX = 4, NQ = 2, NP = 9;
-  using Consts = SinglePendulumGenConsts<R>;
+  using Consts = SingleGenConsts<R>;
+  using Sp = SinglePendulumMFSparsity;
   template <typename P>
   __host__ __device__ static Consts make(const P* p) {
-    return single_pendulum_gen_consts<R, P>(p);
+    Consts k;
+    k.g = single_pendulum_mf_consts<R, P>(p);
+    k.inv_m00 = R(P(1) / (p[0] + p[1]));
+    return k;
+  }
+  template <bool WITH_J, bool HAS_EXT>
+  __device__ __forceinline__ static void accel_sc(const Consts& k, const R s, const R c, const R (&x)[NX], const R u,
+                                                  const ExtForce<R>& fe, R (&a)[NQ], R (&Ja)[NQ][NX], R (&Jua)[NQ]) {
+    R tv, n, inv_n, sr, sl, on_r, on_l, vx, vy;
+    single_pendulum_mf_helpers<R, WITH_J>(k.g, s, c, x[0], x[2], x[3], tv, n, inv_n, sr, sl, on_r, on_l, vx, vy);
+    R M[4], F[2], dFdx[8], dM1[4];
+    if constexpr (HAS_EXT)
+      single_pendulum_mf_terms_ext<R, WITH_J>(k.g, s, c, tv, n, inv_n, sr, sl, on_r, on_l, vx, vy, x[2], x[3], u, fe.fbx, fe.fmx, fe.fmy,
+                                              M, F, dFdx, dM1);
+    else
+      single_pendulum_mf_terms_noext<R, WITH_J>(k.g, s, c, tv, n, inv_n, sr, sl, on_r, on_l, vx, vy, x[2], x[3], u, R(0), R(0), R(0), M,
+                                                F, dFdx, dM1);
+    // LDL^T of the 2 x 2 mass matrix: d0 = M_00 and 1 / d0 are parameters
+    const R L = M[2] * k.inv_m00;
+    const R id1 = Math<R>::rcp(M[3] - L * M[2]);
+    {
+      const R y1 = (F[1] - L * F[0]) * id1;
+      a[1] = y1;
+      a[0] = F[0] * k.inv_m00 - L * y1;
+    }
+    if (WITH_J) {
+#pragma unroll
+      for (int cc = 0; cc < NX; ++cc) {
+        R r[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          bool have = Sp::dFdx[i * 4 + cc];
+          R v = have ? dFdx[i * 4 + cc] : R(0);
+          if (cc == 1) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              if (Sp::dM1[i * 2 + j]) {
+                v = have ? v - dM1[i * 2 + j] * a[j] : -(dM1[i * 2 + j] * a[j]);
+                have = true;
+              }
+          }
+          r[i] = v;
+        }
+        const R y1 = (r[1] - L * r[0]) * id1;
+        Ja[1][cc] = y1;
+        Ja[0][cc] = r[0] * k.inv_m00 - L * y1;
+      }
+      const R y1 = -L * id1;  // M^-1 e_0: the control acts on the base only (checked by the generator)
+      Jua[1] = y1;
+      Jua[0] = k.inv_m00 - L * y1;
+    }
   }
   template <bool WITH_J, bool HAS_EXT>
   __device__ __forceinline__ static void accel(const Consts& k, const R (&x)[NX], const R u,
                                                const ExtForce<R>& fe, R (&a)[NQ], R (&Ja)[NQ][NX],
                                                R (&Jua)[NQ]) {
-    if constexpr (HAS_EXT)
-      single_pendulum_gen_accel_ext<R, WITH_J>(k, x[0], x[1], x[2], x[3], u, fe.fbx, fe.fmx, fe.fmy, a, Ja, Jua);
-    else
-      single_pendulum_gen_accel_noext<R, WITH_J>(k, x[0], x[1], x[2], x[3], u, R(0), R(0), R(0), a, Ja, Jua);
+    R s, c;
+    Math<R>::sincos(x[1], s, c);
+    accel_sc<WITH_J, HAS_EXT>(k, s, c, x, u, fe, a, Ja, Jua);
   }
-  using StepCache = NoStepCache;
-  __device__ __forceinline__ static void chain_begin(StepCache&, const R (&)[NX]) {}
+  using StepCache = TrigBase<R>;
+  __device__ __forceinline__ static void chain_begin(StepCache& sc, const R (&x)[NX]) {
+    if constexpr (Math<R>::kIncrementalTrig && CPMPC_F64_TRIG_CHAIN == 2) {
+      Math<R>::sincos(x[1], sc.s0, sc.c0);
+      sc.th0 = x[1];
+      sc.valid = true;
+    }
+  }
   template <bool WITH_J, bool HAS_EXT, int STAGE>
   __device__ __forceinline__ static void accel_stage(const Consts& k, const R (&x)[NX], const R u,
                                                      const ExtForce<R>& fe, R (&a)[NQ], R (&Ja)[NQ][NX],
-                                                     R (&Jua)[NQ], StepCache&) {
-    accel<WITH_J, HAS_EXT>(k, x, u, fe, a, Ja, Jua);
+                                                     R (&Jua)[NQ], StepCache& sc) {
+    R s, c;
+    stage_sincos<R, STAGE>(sc, x[1], s, c);
+    accel_sc<WITH_J, HAS_EXT>(k, s, c, x, u, fe, a, Ja, Jua);
   }
 };
 

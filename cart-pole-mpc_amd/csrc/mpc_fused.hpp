@@ -280,21 +280,17 @@ __host__ __device__ constexpr bool fused_lean() {
 // layout above) and the 1/d_k of a lane's controls in registers, a wave needs u + du + Gamma = (8 + 8 + 48) x SP x 64 bytes
 // = 40 KB at SP = 10 instead of 60 KB: four waves per CU -- one per SIMD, all the 512-register kernel can use -- instead of
 // two.  Not for the REFINE instantiation (its second solve needs gw and du side by side).
-// The float kernel of the 6-state model takes the same layout (with 24-byte Gamma columns: 320 B per lane, 20 KB per wave,
-// eight waves per CU) AND a register budget of 256, so that two of its waves share a SIMD like the 4-state float kernel's
-// do (CPMPC_FUSED_SLIM_F32_NX6; one wave issues an instruction every 5.1 cycles at best, a SIMD takes one every 2).
+// (Round 5 also tried the float 6-state kernel in this layout with a 256-register budget, two waves per SIMD: 533 spilled
+// dwords, 33 against 51 M re-plans/s; the option was removed in round 6, HISTORY.md has the numbers.)
 #ifndef CPMPC_FUSED_SLIM_F64_NX6
 #define CPMPC_FUSED_SLIM_F64_NX6 1
 #endif
-#ifndef CPMPC_FUSED_SLIM_F32_NX6
-#define CPMPC_FUSED_SLIM_F32_NX6 0
-#endif
 template <typename R, typename M, int SP, bool REFINE>
 __host__ __device__ constexpr bool fused_slim() {
-  return (sizeof(R) == 8 ? CPMPC_FUSED_SLIM_F64_NX6 : CPMPC_FUSED_SLIM_F32_NX6) && M::NX > 4 && !REFINE && SP <= 10;
+  return CPMPC_FUSED_SLIM_F64_NX6 && sizeof(R) == 8 && M::NX > 4 && !REFINE && SP <= 10;
 }
 #undef CPMPC_FUSED_BOUNDS
-#define CPMPC_FUSED_BOUNDS_S __launch_bounds__(64, (fused_lean<R, M, SP>() ? 3 : ((sizeof(R) == 4 && (M::NX <= 4 || fused_slim<R, M, SP, REFINE>())) ? CPMPC_FUSED_WAVES_F32 : 1)))
+#define CPMPC_FUSED_BOUNDS_S __launch_bounds__(64, (fused_lean<R, M, SP>() ? 3 : ((sizeof(R) == 4 && M::NX <= 4) ? CPMPC_FUSED_WAVES_F32 : 1)))
 #define CPMPC_FUSED_BOUNDS __launch_bounds__(64, ((sizeof(R) == 4 && M::NX <= 4) ? CPMPC_FUSED_WAVES_F32 : 1))
 
 // ---- Gamma in LDS ---------------------------------------------------------------------------------------------------

@@ -29,6 +29,9 @@ std::string NLSSolverOutputs::ToString() const {
   std::ostringstream os;
   os << "Iterations: " << iterations << ", termination = " << TerminationName(termination_state)
      << "\n  final cost (1/2 |r|^2) = " << final_cost << ", final |c|_1 = " << final_equality_l1 << "\n";
+  if (horizon_beyond_parity)
+    os << "  horizon beyond " << cpmpc_max_parity_horizon()
+       << " s (cpmpc_max_parity_horizon): far from the optimum a cold start may differ from a full-space solve by more than 1e-5\n";
   return os.str();
 }
 
@@ -76,6 +79,8 @@ Optimization::Optimization(const OptimizationParams& params, std::size_t max_bat
 
 Optimization::~Optimization() { cpmpc_destroy(solver_); }
 
+bool Optimization::HorizonBeyondParity() const noexcept { return cpmpc_horizon_beyond_parity(solver_) == 1; }
+
 void Optimization::Reset() {
   previous_solution_.resize(0);
   cpmpc_reset(solver_);
@@ -113,6 +118,7 @@ OptimizationOutputs Optimization::Step(const SingleCartPoleState& current_state,
   out.solver_outputs.iterations = iterations;
   out.solver_outputs.final_cost = cost;
   out.solver_outputs.final_equality_l1 = eq;
+  out.solver_outputs.horizon_beyond_parity = HorizonBeyondParity();
   out.u = std::move(u);
   out.predicted_states.reserve(N);
   for (std::size_t k = 0; k < N; ++k)  // [N][4][1]

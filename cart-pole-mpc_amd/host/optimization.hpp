@@ -53,6 +53,8 @@ struct NLSSolverOutputs {
   int iterations{0};
   double final_cost{0.0};         // 1/2 |r|^2
   double final_equality_l1{0.0};  // |c|_1
+  // the handle's horizon is beyond cpmpc_max_parity_horizon() (include/cpmpc.h: cpmpc_horizon_beyond_parity): ToString says so
+  bool horizon_beyond_parity{false};
   std::string ToString() const;
 };
 
@@ -135,6 +137,9 @@ class Optimization {
   // problems per chunk of a pipelined host-pointer step (0 = never split)
   void SetHostChunk(std::size_t problems);
   std::size_t Dim() const;
+  // window_length * control_dt exceeds cpmpc_max_parity_horizon(): solved as asked, a few cold starts in 10^4 may differ from a
+  // full-space solve by more than 1e-5 (include/cpmpc.h: cpmpc_horizon_beyond_parity); also in every Step's solver_outputs
+  [[nodiscard]] bool HorizonBeyondParity() const noexcept;
 
   const OptimizationParams& params() const noexcept { return params_; }
 

@@ -148,7 +148,9 @@ PYBIND11_MODULE(pypendulum, m) {
       .def("set_previous_solution", &Optimization::SetPreviousSolution)
       .def("set_previous_solution_batch", &Optimization::SetPreviousSolutionBatch, py::arg("z_soa"), py::arg("batch"))
       .def("get_solution_batch", &Optimization::GetSolutionBatch, py::arg("batch"))
-      .def("set_host_chunk", &Optimization::SetHostChunk, py::arg("problems"));
+      .def("set_host_chunk", &Optimization::SetHostChunk, py::arg("problems"))
+      // the handle's horizon exceeds cpmpc_max_parity_horizon() (include/cpmpc.h): a per-object status, also in solver_summary()
+      .def_property_readonly("horizon_beyond_parity", &Optimization::HorizonBeyondParity);
 
   py::class_<BatchArrays>(m, "BatchArrays")
       .def_readonly("batch", &BatchArrays::batch)

@@ -148,7 +148,7 @@ void cpmpc_destroy(cpmpc_solver* s);
  *   opts_size  sizeof(cpmpc_solver_opts) as the CALLER was compiled (0 = this header's).  Option fields are only ever
  *              appended; a caller built against an earlier header passes its shorter size and keeps the library's
  *              defaults for the fields it does not know (full_step_below was appended in round 3, exit_defect_floor in
- *              round 4).  Must be the size of the struct in some release: 8 + 8 k bytes, 104 <= size <= this header's.
+ *              round 4).  Must be the size of the struct in some release: 8 + 8 k bytes, 112 (the fields through u_limit) <= size <= this header's.
  *              Always start from cpmpc_default_solver_opts: a zero-initialised struct is NOT the defaults.
  *              The positional constructors (cpmpc_create, cpmpc_create_model, cpmpc_sharded_create) cannot be told the
  *              caller's size: they read CPMPC_SOLVER_OPTS_SIZE_POSITIONAL bytes -- the struct as it was when they were
@@ -192,6 +192,13 @@ int cpmpc_create_ex(const cpmpc_create_info* info, cpmpc_solver** out);
 /* bytes of cpmpc_solver_opts the positional constructors read (the struct through full_step_below) */
 #define CPMPC_SOLVER_OPTS_SIZE_POSITIONAL 128u
 int cpmpc_refines_qp(const cpmpc_solver* s); /* 1: this handle's kernels refine the QP solution (CPMPC_CREATE_REFINE_QP) */
+/* The solver options a handle actually uses -- this library's defaults overlaid with as many leading bytes of the caller's
+ * struct as its constructor read: the positional constructors (cpmpc_create, cpmpc_create_model, cpmpc_sharded_create) read
+ * CPMPC_SOLVER_OPTS_SIZE_POSITIONAL bytes, so a field appended later (exit_defect_floor) set through them is NOT taken and
+ * keeps its default; cpmpc_create_ex reads opts_size.  out_size: sizeof of the caller's struct (112 .. sizeof here, 8 + 8 k).
+ * A struct shorter than 112 bytes (the 13 doubles through u_limit: the shortest layout that is a prefix of today's) is
+ * refused by every constructor. */
+int cpmpc_get_solver_opts(const cpmpc_solver* s, cpmpc_solver_opts* out, size_t out_size);
 /* CPMPC_CREATE_WIDE_QP / CPMPC_CREATE_NO_WIDE_QP (CPMPC_F32 handles; ignored by CPMPC_F64 ones): force on / off that the fused
  * kernels carry the whole terminal part of the QP in double -- the products of transition matrices across the shooting
  * intervals, the columns of U^-1 R^T, the multipliers and their effect on the step -- not only the NX x NX system.  It is
@@ -206,13 +213,25 @@ int cpmpc_refines_qp(const cpmpc_solver* s); /* 1: this handle's kernels refine 
  *                                for 0 - 5 % (51.0 -> 50.8 M near upright, 50.9 -> 48.3 M from within 0.5 rad).
  * DEFAULT (neither flag): ON for the 6-state model -- without it four of five float solves of that model are off by more
  * than 0.01 N after five iterations -- and OFF for the 4-state one (the reference's model: speed first, the bar of this
- * path is met by CPMPC_F64 handles).  Both pipelines since round 6: a float handle that AUTO or cpmpc_set_pipeline() sends to
+ * path is met by CPMPC_F64 handles; a caller who re-plans from cold starts in single precision should pass the flag: 3.8 %
+ * of the throughput for 93.7 -> 99.4 % of the problems within 1e-2 of the double answer).  The option belongs to the handle,
+ * not to the step: "on for cold-start steps only" was tried in round 6 and withdrawn (a problem's arithmetic would then depend
+ * on which other problems share its call).  Both pipelines since round 6: a float handle that AUTO or cpmpc_set_pipeline() sends to
  * the split pipeline (state spacings the fused kernel is not built for) runs qp_ls_kernel's wide form -- the same quantities
  * in double, one more pass over the workspace -- and lands where the fused one does (tests/test_gpu_round6.py: the 6-state
  * model at state_spacing 20 against the float CPU check).  cpmpc_wide_qp() tells what a handle does, in either pipeline. */
 int cpmpc_wide_qp(const cpmpc_solver* s);
 /* seconds: the longest horizon held to 1e-5 of the CPU check on every problem (1.0) */
 double cpmpc_max_parity_horizon(void);
+/* 1: this handle's horizon window_length * control_dt is beyond cpmpc_max_parity_horizon() -- a PER-HANDLE status (round 6;
+ * the once-per-process line on stderr is easy to miss in a notebook): such a handle is solved as asked, with the QP
+ * refinement of CPMPC_CREATE_REFINE_QP on by default (CPMPC_F64), and on a few cold starts in 10^4 far from the optimum its
+ * controls may differ from a full-space solve by more than 1e-5 (measured at 1.6 s, three iterations: 3 of 8 192 lanes
+ * with the kernels at fault by the extended-precision arbiter, 34 without the refinement; a dense pivoted solve in double is
+ * itself up to 6.6e-5 from the extended-precision answer there).  pendulum::Optimization::HorizonBeyondParity(), the
+ * `horizon_beyond_parity` attribute of pypendulum.Optimization and a line in solver_summary() carry it to the caller.
+ * 0: within the bound; -1: null handle.  Replaces nothing in the reference (optimization.cc:13-22 accepts any horizon). */
+int cpmpc_horizon_beyond_parity(const cpmpc_solver* s);
 
 /* 2: register-resident linearisation compiled for this spacing (1,2,4,5,8,10,20); 1: served by the generic
  * run-time-spacing kernel; 0: not a valid spacing */

@@ -87,6 +87,7 @@ def test_final_line_is_short(world, tmp_path):
     assert c["fp64_value"] == pytest.approx(50234567.89, rel=1e-5) and c["fp64_frac"] == pytest.approx(0.381235, rel=1e-5)
     assert c["parity_f64_lanes_over_1e-5"] == 0 and c["wide_qp_f32_value"] == pytest.approx(117912345.6, rel=1e-5)
     assert c["wide_qp_f32_within_1e-2"] == pytest.approx(0.99426) and c["detail"] == "bench_detail.json"
+    assert c["f32_within_1e-2"] == pytest.approx(0.9366)
     if world > 1:
         assert c["backend"] == "nccl" and c["rank_ms_per_step_max"] == pytest.approx(2.16988, rel=1e-5)
     assert "variants" not in c and "note" not in c["roofline"] and "distributed" not in c

@@ -143,6 +143,8 @@ def test_long_horizons_are_accepted_and_refused_only_when_asked(lib, pkg, capfd)
     is CPMPC_ERR_UNSUPPORTED with the reason in the message.  The versioned structs reject a wrong struct_size / opts_size.
     (No device is needed for any of it.)"""
     assert lib.cpmpc_max_parity_horizon() == pytest.approx(1.0)
+    assert lib.cpmpc_horizon_beyond_parity(None) == -1   # the per-handle status (round 6) of no handle
+    assert lib.cpmpc_get_solver_opts(None, None, 0) == pkg.capi.ERR_INVALID_ARG
     h = C.c_void_p()
     past = (pkg.capi.OK, pkg.capi.ERR_NO_DEVICE)
     for over in (dict(window_length=160), dict(window_length=120, state_spacing=12), dict(control_dt=0.05)):
@@ -189,10 +191,12 @@ def test_long_horizons_are_accepted_and_refused_only_when_asked(lib, pkg, capfd)
     o = pkg.capi.default_solver_opts()
     assert lib.cpmpc_create_ex(C.byref(info(flags=1, opts=C.pointer(o), opts_size=C.sizeof(o) + 8)),
                                C.byref(h)) == pkg.capi.ERR_INVALID_ARG
-    # a size that is nobody's struct: it splits a double, or is shorter than the first release's
-    for bad in (4, 100, C.sizeof(o) - 4):
+    # a size that is nobody's struct: it splits a double, or is shorter than the shortest layout that is a prefix of today's
+    # (8 + 13 doubles, through u_limit = 112 bytes; the 104 bytes of the very first commit had no ls_alpha_growth: ADVICE r4, r5)
+    assert pkg.capi.SolverOpts.u_limit.offset + 8 == 112
+    for bad in (4, 100, 104, C.sizeof(o) - 4):
         assert lib.cpmpc_create_ex(C.byref(info(opts=C.pointer(o), opts_size=bad)), C.byref(h)) == pkg.capi.ERR_INVALID_ARG, bad
-    for good in (104, pkg.capi.SOLVER_OPTS_SIZE_POSITIONAL, C.sizeof(o)):
+    for good in (112, pkg.capi.SOLVER_OPTS_SIZE_POSITIONAL, C.sizeof(o)):
         rc = lib.cpmpc_create_ex(C.byref(info(opts=C.pointer(o), opts_size=good)), C.byref(h))
         assert rc in past, good
         if h.value:

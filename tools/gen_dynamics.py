@@ -308,7 +308,7 @@ def emit_hip_sc(model, header):
 # ------------------------------------------------------------------------------------------------------------------
 # cart + single pole with dissipation, springs and external forces (symbolic/dynamics_single.py:58-143)
 # ------------------------------------------------------------------------------------------------------------------
-def derive_single():
+def derive_single(factored_velocity=False):
     """Accelerations a = (b_x'', th_1'') and their partials wrt x = (b_x, th_1, b_x', th_1') and u, as expressions in
     the state, the control, the external forces, the parameters and these helper symbols (evaluated by the emitted
     prologue, differentiated by the rules below):
@@ -339,8 +339,12 @@ def derive_single():
     Q_th = fmx * d_th(p1[0]) + fmy * d_th(p1[1])
     F_fric = -mu_b * (m_1 + m_b) * g * tv                                # :100-103
     # drag power (1/6) c_d |p_1'|^3 enters through d/dq' : (1/2) c_d |p_1'|^2 d|p_1'|/dq' = (1/2) c_d n (p_1' . dp_1'/dq')
-    drag_v = sp.Rational(1, 2) * c_d_1 * n * (p1d[0] * sp.diff(p1d[0], v) + p1d[1] * sp.diff(p1d[1], v))     # :105-111
-    drag_w = sp.Rational(1, 2) * c_d_1 * n * (p1d[0] * sp.diff(p1d[0], w) + p1d[1] * sp.diff(p1d[1], w))
+    # factored_velocity (the M / F form of round 6): the components of p_1' stay the symbols vxs, vys in the drag terms (with
+    # their derivative rules below) instead of being expanded into the state -- what a person would write
+    vxs, vys = sp.symbols("vx vy", real=True)
+    pv = (vxs, vys) if factored_velocity else (p1d[0], p1d[1])
+    drag_v = sp.Rational(1, 2) * c_d_1 * n * (pv[0] * sp.diff(p1d[0], v) + pv[1] * sp.diff(p1d[1], v))     # :105-111
+    drag_w = sp.Rational(1, 2) * c_d_1 * n * (pv[0] * sp.diff(p1d[0], w) + pv[1] * sp.diff(p1d[1], w))
     F_s = -k_s * sr + k_s * sl                                           # :113-115
     el_b = ddt(sp.diff(L, v)) - sp.diff(L, bx) - u - Q_b - F_fric - F_s + drag_v      # :117-131
     el_th = ddt(sp.diff(L, w)) - d_th(L) - Q_th + drag_w
@@ -355,25 +359,31 @@ def derive_single():
     # total derivatives through the helper symbols
     vx, vy = p1d[0].subs({a0: 0, a1: 0}), p1d[1].subs({a0: 0, a1: 0})
 
+    def dvel(var):   # d p_1' / d var
+        return (d_th(vx) if var is th else sp.diff(vx, var)), (d_th(vy) if var is th else sp.diff(vy, var))
+
     def dn(var):   # d|p_1'| / d var,  var in (th, v, w)
-        dvx = d_th(vx) if var is th else sp.diff(vx, var)
-        dvy = d_th(vy) if var is th else sp.diff(vy, var)
-        return (vx * dvx + vy * dvy) * inv_n
+        dvx, dvy = dvel(var)
+        return ((pv[0] if factored_velocity else vx) * dvx + (pv[1] if factored_velocity else vy) * dvy) * inv_n
+
+    def through_velocity(e, var):   # the chain rule through the symbols vxs, vys (zero when they are not in use)
+        dvx, dvy = dvel(var)
+        return sp.diff(e, vxs) * dvx + sp.diff(e, vys) * dvy
 
     def total(e, var):
         if var is bx:
             return sp.diff(e, bx) + sp.diff(e, sr) * on_r - sp.diff(e, sl) * on_l
         if var is th:
-            return d_th(e) + sp.diff(e, n) * dn(th)
+            return d_th(e) + sp.diff(e, n) * dn(th) + through_velocity(e, th)
         if var is v:
-            return sp.diff(e, v) + sp.diff(e, tv) * (1 - tv**2) * ivm + sp.diff(e, n) * dn(v)
-        return sp.diff(e, w) + sp.diff(e, n) * dn(w)
+            return sp.diff(e, v) + sp.diff(e, tv) * (1 - tv**2) * ivm + sp.diff(e, n) * dn(v) + through_velocity(e, v)
+        return sp.diff(e, w) + sp.diff(e, n) * dn(w) + through_velocity(e, w)
 
     Ja = sp.Matrix(2, 4, lambda r, k: total(acc[r], (bx, th, v, w)[k]))
     Jua = sp.Matrix([sp.diff(acc[0], u), sp.diff(acc[1], u)])
     return dict(prm=list(prm), state=[bx, th, v, w], u=u, ext=[fbx, fmx, fmy], acc=acc, Ja=Ja, Jua=Jua,
                 helpers=dict(s=s, c=c, tv=tv, n=n, inv_n=inv_n, sr=sr, sl=sl, on_r=on_r, on_l=on_l, ivm=ivm),
-                vx=vx, vy=vy)
+                vx=vx, vy=vy, el=el, acc_syms=(a0, a1), total=total, d_th=d_th, vel_syms=(vxs, vys))
 
 
 def cse_single(model):
@@ -459,7 +469,7 @@ def write_single(model):
         const_expr[sym] = ce
     vx, vy = model["vx"], model["vy"]
     files = {}
-    for lang in ("c", "hip"):
+    for lang in ("c",):
         scalar = "double" if lang == "c" else "R"
         pr = _Printer(scalar)
         z, one = ("%s(0)" % scalar, "%s(1)" % scalar) if lang == "hip" else ("0.0", "1.0")
@@ -542,9 +552,183 @@ def write_single(model):
         if lang == "hip":
             lines.append("}  // namespace cpmpc")
         files[lang] = "\n".join(lines) + "\n"
+    files["hip"] = "\n".join([
+        "// GENERATED by tools/gen_dynamics.py from the Lagrangian of symbolic/dynamics_single.py:58-143 -- do not edit.",
+        "// M(q) q'' = F(q, q', u, external forces) of the cart + single pole with friction, drag, bumpers: M[4], F[2], dFdx[2x4]",
+        "// (x = b_x, th_1, b_x', th_1'), dM1 = dM/dth_1, row-major; the accelerations and their partials come from the 2 x 2 solve",
+        "// next to this code (models.hpp: SingleModelGenerated), as for the 6-state model.  (Rounds 2-5 emitted the reference",
+        "// generator's own form here -- closed-form inverse, symbolic Jacobians, symbolic/sympy_utils.py:43-50; the C file for the",
+        "// CPU check, oracle/single_pendulum_gen.inc, still is that form.)",
+        "#pragma once", "namespace cpmpc {", emit_single_mf(model).rstrip("\n"), "}  // namespace cpmpc"]) + "\n"
     write_if_changed(os.path.join(ROOT, "oracle", "single_pendulum_gen.inc"), files["c"])
     write_if_changed(os.path.join(ROOT, "cart-pole-mpc_amd", "csrc", "single_pendulum_gen.hpp"), files["hip"])
     return files
+
+
+def emit_single_mf(model):
+    """Round 6: the 4-state model in the SAME form as the 6-state one -- M(q) q'' = F with the solve left to hand-written code
+    next to it (models.hpp: SingleModelGenerated) -- instead of the closed-form inverse and its symbolic derivatives:
+    M (2 x 2), F (2), dF/dx (2 x 4) and dM/dth_1 (2 x 2) as polynomials in the per-lane atoms (s, c, the helper symbols of
+    derive_single, velocities, control, external forces) with parameter-only coefficients folded into constants (host), sine
+    and cosine as INPUTS (the RK4 stages rotate them, models.hpp: StepCache), identically-zero entries as masks.  The helper
+    prologue (tanh, |p_1'| and its reciprocal, the bumper selects) is emitted as its own function."""
+    model = derive_single(factored_velocity=True)
+    bx, th, v, w = model["state"]
+    u = model["u"]
+    fbx, fmx, fmy = model["ext"]
+    h = model["helpers"]
+    vxs, vys = model["vel_syms"]
+    s_, c_, tv, n, inv_n, sr, sl, on_r, on_l, ivm = (h[k] for k in ("s", "c", "tv", "n", "inv_n", "sr", "sl", "on_r", "on_l", "ivm"))
+    prm = model["prm"]
+    el, a_syms, total, d_th = model["el"], model["acc_syms"], model["total"], model["d_th"]
+    M = sp.Matrix(2, 2, lambda i, j: sp.diff(el[i], a_syms[j]))
+    F = sp.Matrix([-(e.subs({a_syms[0]: 0, a_syms[1]: 0})) for e in el])
+    x = [bx, th, v, w]
+    outs = [("M[%d]" % (i * 2 + j), M[i, j]) for i in range(2) for j in range(2)]
+    outs += [("F[%d]" % i, F[i]) for i in range(2)]
+    outs += [("dFdx[%d]" % (i * 4 + c), total(F[i], x[c])) for i in range(2) for c in range(4)]
+    outs += [("dM1[%d]" % (i * 2 + j), d_th(M[i, j])) for i in range(2) for j in range(2)]
+    outs += [("dFdu[%d]" % i, sp.diff(F[i], u)) for i in range(2)]
+    lane_syms = [s_, c_, tv, n, inv_n, sr, sl, on_r, on_l, vxs, vys, v, w, u, fbx, fmx, fmy]
+    pset = list(prm) + [ivm]
+
+    def trig_reduce(e):   # c^2 -> 1 - s^2 (the polynomial expansion does not know the identity)
+        e = sp.expand(e)
+        e = e.replace(lambda t: t.is_Pow and t.base == c_ and t.exp.is_Integer and t.exp >= 2,
+                      lambda t: (1 - s_**2) ** (int(t.exp) // 2) * c_ ** (int(t.exp) % 2))
+        return sp.expand(e)
+    files = {}
+    text = ["// ---- round 6: M(q) q'' = F form with constants folded, sine / cosine and the helper terms as inputs, structure as masks ----"]
+    kconst = {}
+
+    def const_of(e):
+        e = sp.factor(e)
+        num, rest = e.as_coeff_Mul()
+        if rest == 1:
+            return sp.Integer(1), num
+        key = sp.expand(rest)
+        try:
+            lead = sp.Poly(key, *pset).coeffs()[0]
+        except sp.PolynomialError:
+            lead = 1
+        if lead.is_number and lead < 0:
+            key, num = -key, -num
+        if key not in kconst:
+            kconst[key] = sp.Symbol("k%d" % len(kconst), real=True)
+        return kconst[key], num
+
+    specs = {}
+    for with_ext in (False, True):
+        zero = {} if with_ext else {fbx: 0, fmx: 0, fmy: 0}
+        lane_exprs = []
+        for _, e in outs:
+            e = trig_reduce(e.subs(zero))
+            if e == 0:
+                lane_exprs.append(sp.Integer(0))
+                continue
+            poly = sp.Poly(e, *lane_syms)
+            acc = 0
+            for mono, coeff in poly.terms():
+                ksym, num = const_of(coeff)
+                term = num * ksym
+                for sym, pw in zip(lane_syms, mono):
+                    term = term * sym**pw
+                acc = acc + term
+            lane_exprs.append(acc)
+        repl, red = sp.cse(lane_exprs, symbols=sp.numbered_symbols("t"), optimizations="basic")
+        specs[with_ext] = (repl, red)
+    names = [nm for nm, _ in outs]
+    pr, prc = _Printer("R"), _Printer("P")
+    const_syms = list(kconst.values())
+    text += ["template <typename R>", "struct SinglePendulumMFConsts {", "  R k[%d];" % max(len(const_syms), 1),
+             "  R ivm, tanh_k2, x_s, l_1;  // helper prologue: friction scale, bumper position, pole length (|p_1'|)", "};",
+             "template <typename R, typename P>",
+             "__host__ __device__ inline SinglePendulumMFConsts<R> single_pendulum_mf_consts(const P* q) {",
+             "  SinglePendulumMFConsts<R> K;"]
+    for i, sym in enumerate(prm):
+        text.append("  const P %s = q[%d];" % (sym, i))
+    text.append("  const P ivm = P(1) / ((P(1.0e-6) < v_mu_b) ? v_mu_b : P(1.0e-6));  // 1 / max(v_mu_b, 1e-6)")
+    for i, (ce, sym) in enumerate(kconst.items()):
+        text.append("  K.k[%d] = R(%s);" % (i, prc.doprint(ce)))
+    text += ["  K.ivm = R(ivm);", "  K.tanh_k2 = R(P(-2.8853900817779268) * ivm);  // fp32 tanh: exp2 argument scale",
+             "  K.x_s = R(x_s);", "  K.l_1 = R(l_1);",
+             "  " + " ".join("(void)%s;" % p_ for p_ in prm), "  return K;", "}"]
+    # structure (of the no-ext form; the external forces add no new non-zero entries to these masks' meaning for the solver:
+    # the masks are taken over BOTH specialisations)
+    nz = {nm: any(specs[w][1][i] != 0 for w in (False, True)) for i, nm in enumerate(names)}
+
+    def mask(prefix, count):
+        return "{" + ", ".join("true" if nz["%s[%d]" % (prefix, i)] else "false" for i in range(count)) + "}"
+
+    ja_zero = []
+    for c in range(4):
+        z = all(not nz["dFdx[%d]" % (i * 4 + c)] for i in range(2))
+        if c == 1:
+            z = z and all(not nz["dM1[%d]" % i] for i in range(4))
+        ja_zero.append(z)
+    text += ["struct SinglePendulumMFSparsity {", "  static constexpr bool dFdx[8] = %s;" % mask("dFdx", 8),
+             "  static constexpr bool dM1[4] = %s;" % mask("dM1", 4),
+             "  static constexpr unsigned ja_zero_cols = 0x%xu;" % sum(1 << c for c in range(4) if ja_zero[c]), "};",
+             "// the helper terms of the dynamics at a state: tv = tanh(b_x' / max(v_mu_b, 1e-6)), n = |p_1'| (inv_n its reciprocal, 0 at",
+             "// rest: the |v|^2 > 0 guard; WITH_J = false skips it), the bumper springs' compressions and their 0 / 1 slopes",
+             "template <typename R, bool WITH_J>",
+             "__device__ __forceinline__ void single_pendulum_mf_helpers(const SinglePendulumMFConsts<R>& K, const R s, const R c, const R b_x, "
+             "const R b_x_dot, const R th_1_dot, R& tv, R& n, R& inv_n, R& sr, R& sl, R& on_r, R& on_l, R& vx, R& vy) {",
+             "  tv = Math<R>::tanh_scaled(b_x_dot, K.ivm, K.tanh_k2);",
+             "  const R e_r = b_x - K.x_s, e_l = -K.x_s - b_x;  // strict comparisons, as the reference's generated branches",
+             "  const bool is_r = R(0) < e_r, is_l = R(0) < e_l;",
+             "  sr = is_r ? e_r : R(0);", "  sl = is_l ? e_l : R(0);", "  on_r = is_r ? R(1) : R(0);", "  on_l = is_l ? R(1) : R(0);",
+             "  vx = b_x_dot - K.l_1 * s * th_1_dot;", "  vy = K.l_1 * c * th_1_dot;",
+             "  const R n2 = vx * vx + vy * vy;",
+             "  if (WITH_J) Math<R>::sqrt_inv(n2, n, inv_n);", "  else {", "    n = Math<R>::sqrt_only(n2);", "    inv_n = R(0);", "  }", "}"]
+    for with_ext in (False, True):
+        repl, red = specs[with_ext]
+        used = set()
+        for _, e in repl:
+            used |= e.free_symbols
+        for e in red:
+            used |= e.free_symbols
+        tag = "ext" if with_ext else "noext"
+        text += ["template <typename R, bool WITH_J>",
+                 "__device__ __forceinline__ void single_pendulum_mf_terms_%s(const SinglePendulumMFConsts<R>& K, const R s, const R c, "
+                 "const R tv, const R n, const R inv_n, const R sr, const R sl, const R on_r, const R on_l, const R vx, const R vy, const R b_x_dot, "
+                 "const R th_1_dot, const R u, const R f_b_x, const R f_m1_x, const R f_m1_y, R* M, R* F, R* dFdx, R* dM1) {" % tag]
+        for i, sym in enumerate(const_syms):
+            if sym in used:
+                text.append("  const R %s = K.k[%d];" % (sym, i))
+        # temporaries needed by M and F first, the rest only with Jacobians
+        dep = {sym: e.free_symbols for sym, e in repl}
+
+        def closure(exprs):
+            need, stack = set(), [t for e in exprs for t in e.free_symbols]
+            while stack:
+                t = stack.pop()
+                if t in dep and t not in need:
+                    need.add(t)
+                    stack.extend(dep[t])
+            return need
+
+        n_val = 6   # M[4], F[2]
+        need_a = closure(red[:n_val])
+        for sym, e in repl:
+            if sym in need_a:
+                text.append("  const R %s = %s;" % (sym, pr.doprint(e)))
+        for nm, e in zip(names[:n_val], red[:n_val]):
+            text.append("  %s = %s;" % (nm, pr.doprint(e)))
+        text.append("  if (WITH_J) {")
+        for sym, e in repl:
+            if sym not in need_a:
+                text.append("    const R %s = %s;" % (sym, pr.doprint(e)))
+        for nm, e in zip(names[n_val:], red[n_val:]):
+            if nm.startswith("dFdu"):
+                continue
+            if e != 0:
+                text.append("    %s = %s;" % (nm, pr.doprint(e)))
+        text += ["  }", "  (void)s; (void)c; (void)tv; (void)n; (void)inv_n; (void)sr; (void)sl; (void)on_r; (void)on_l; (void)vx; (void)vy; (void)b_x_dot; "
+                 "(void)th_1_dot; (void)u; (void)f_b_x; (void)f_m1_x; (void)f_m1_y; (void)dFdx; (void)dM1;", "}"]
+        dfdu = [red[names.index("dFdu[%d]" % i)] for i in range(2)]
+        assert dfdu[0] == 1 and dfdu[1] == 0, dfdu   # the control acts on the base only: da/du = M^-1 e_0 (the solver assumes it)
+    return "\n".join(text) + "\n"
 
 
 def main():
