@@ -557,8 +557,8 @@ def write_single(model):
         "// M(q) q'' = F(q, q', u, external forces) of the cart + single pole with friction, drag, bumpers: M[4], F[2], dFdx[2x4]",
         "// (x = b_x, th_1, b_x', th_1'), dM1 = dM/dth_1, row-major; the accelerations and their partials come from the 2 x 2 solve",
         "// next to this code (models.hpp: SingleModelGenerated), as for the 6-state model.  (Rounds 2-5 emitted the reference",
-        "// generator's own form here -- closed-form inverse, symbolic Jacobians, symbolic/sympy_utils.py:43-50; the C file for the",
-        "// CPU check, oracle/single_pendulum_gen.inc, still is that form.)",
+        "// generator's own form here -- closed-form inverse, symbolic Jacobians, symbolic/sympy_utils.py:43-50; the C file the",
+        "// generator writes for the CPU check still is that form.)",
         "#pragma once", "namespace cpmpc {", emit_single_mf(model).rstrip("\n"), "}  // namespace cpmpc"]) + "\n"
     write_if_changed(os.path.join(ROOT, "oracle", "single_pendulum_gen.inc"), files["c"])
     write_if_changed(os.path.join(ROOT, "cart-pole-mpc_amd", "csrc", "single_pendulum_gen.hpp"), files["hip"])
