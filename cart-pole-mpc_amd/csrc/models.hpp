@@ -87,14 +87,14 @@ struct SingleModelGenerated {
   template <bool WITH_J, bool HAS_EXT>
   __device__ __forceinline__ static void accel_sc(const Consts& k, const R s, const R c, const R (&x)[NX], const R u,
                                                   const ExtForce<R>& fe, R (&a)[NQ], R (&Ja)[NQ][NX], R (&Jua)[NQ]) {
-    R tv, n, inv_n, sr, sl, on_r, on_l, vx, vy;
-    single_pendulum_mf_helpers<R, WITH_J>(k.g, s, c, x[0], x[2], x[3], tv, n, inv_n, sr, sl, on_r, on_l, vx, vy);
+    R tv, sech2, n, inv_n, sr, sl, on_r, on_l, vx, vy;
+    single_pendulum_mf_helpers<R, WITH_J>(k.g, s, c, x[0], x[2], x[3], tv, sech2, n, inv_n, sr, sl, on_r, on_l, vx, vy);
     R M[4], F[2], dFdx[8], dM1[4];
     if constexpr (HAS_EXT)
-      single_pendulum_mf_terms_ext<R, WITH_J>(k.g, s, c, tv, n, inv_n, sr, sl, on_r, on_l, vx, vy, x[2], x[3], u, fe.fbx, fe.fmx, fe.fmy,
+      single_pendulum_mf_terms_ext<R, WITH_J>(k.g, s, c, tv, sech2, n, inv_n, sr, sl, on_r, on_l, vx, vy, x[2], x[3], u, fe.fbx, fe.fmx, fe.fmy,
                                               M, F, dFdx, dM1);
     else
-      single_pendulum_mf_terms_noext<R, WITH_J>(k.g, s, c, tv, n, inv_n, sr, sl, on_r, on_l, vx, vy, x[2], x[3], u, R(0), R(0), R(0), M,
+      single_pendulum_mf_terms_noext<R, WITH_J>(k.g, s, c, tv, sech2, n, inv_n, sr, sl, on_r, on_l, vx, vy, x[2], x[3], u, R(0), R(0), R(0), M,
                                                 F, dFdx, dM1);
     // LDL^T of the 2 x 2 mass matrix: d0 = M_00 and 1 / d0 are parameters
     const R L = M[2] * k.inv_m00;

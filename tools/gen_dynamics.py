@@ -341,8 +341,9 @@ def derive_single(factored_velocity=False):
     # drag power (1/6) c_d |p_1'|^3 enters through d/dq' : (1/2) c_d |p_1'|^2 d|p_1'|/dq' = (1/2) c_d n (p_1' . dp_1'/dq')
     # factored_velocity (the M / F form of round 6): the components of p_1' stay the symbols vxs, vys in the drag terms (with
     # their derivative rules below) instead of being expanded into the state -- what a person would write
-    vxs, vys = sp.symbols("vx vy", real=True)
+    vxs, vys, sech2 = sp.symbols("vx vy sech2", real=True)
     pv = (vxs, vys) if factored_velocity else (p1d[0], p1d[1])
+    dtv = sech2 if factored_velocity else (1 - tv**2)   # d tanh / d arg: a helper of its own in the M / F form (no 1 - tanh^2 cancellation)
     drag_v = sp.Rational(1, 2) * c_d_1 * n * (pv[0] * sp.diff(p1d[0], v) + pv[1] * sp.diff(p1d[1], v))     # :105-111
     drag_w = sp.Rational(1, 2) * c_d_1 * n * (pv[0] * sp.diff(p1d[0], w) + pv[1] * sp.diff(p1d[1], w))
     F_s = -k_s * sr + k_s * sl                                           # :113-115
@@ -376,14 +377,14 @@ def derive_single(factored_velocity=False):
         if var is th:
             return d_th(e) + sp.diff(e, n) * dn(th) + through_velocity(e, th)
         if var is v:
-            return sp.diff(e, v) + sp.diff(e, tv) * (1 - tv**2) * ivm + sp.diff(e, n) * dn(v) + through_velocity(e, v)
+            return sp.diff(e, v) + sp.diff(e, tv) * dtv * ivm + sp.diff(e, n) * dn(v) + through_velocity(e, v)
         return sp.diff(e, w) + sp.diff(e, n) * dn(w) + through_velocity(e, w)
 
     Ja = sp.Matrix(2, 4, lambda r, k: total(acc[r], (bx, th, v, w)[k]))
     Jua = sp.Matrix([sp.diff(acc[0], u), sp.diff(acc[1], u)])
     return dict(prm=list(prm), state=[bx, th, v, w], u=u, ext=[fbx, fmx, fmy], acc=acc, Ja=Ja, Jua=Jua,
                 helpers=dict(s=s, c=c, tv=tv, n=n, inv_n=inv_n, sr=sr, sl=sl, on_r=on_r, on_l=on_l, ivm=ivm),
-                vx=vx, vy=vy, el=el, acc_syms=(a0, a1), total=total, d_th=d_th, vel_syms=(vxs, vys))
+                vx=vx, vy=vy, el=el, acc_syms=(a0, a1), total=total, d_th=d_th, vel_syms=(vxs, vys), sech2=sech2)
 
 
 def cse_single(model):
@@ -578,6 +579,7 @@ def emit_single_mf(model):
     fbx, fmx, fmy = model["ext"]
     h = model["helpers"]
     vxs, vys = model["vel_syms"]
+    sech2 = model["sech2"]
     s_, c_, tv, n, inv_n, sr, sl, on_r, on_l, ivm = (h[k] for k in ("s", "c", "tv", "n", "inv_n", "sr", "sl", "on_r", "on_l", "ivm"))
     prm = model["prm"]
     el, a_syms, total, d_th = model["el"], model["acc_syms"], model["total"], model["d_th"]
@@ -589,7 +591,7 @@ def emit_single_mf(model):
     outs += [("dFdx[%d]" % (i * 4 + c), total(F[i], x[c])) for i in range(2) for c in range(4)]
     outs += [("dM1[%d]" % (i * 2 + j), d_th(M[i, j])) for i in range(2) for j in range(2)]
     outs += [("dFdu[%d]" % i, sp.diff(F[i], u)) for i in range(2)]
-    lane_syms = [s_, c_, tv, n, inv_n, sr, sl, on_r, on_l, vxs, vys, v, w, u, fbx, fmx, fmy]
+    lane_syms = [s_, c_, tv, sech2, n, inv_n, sr, sl, on_r, on_l, vxs, vys, v, w, u, fbx, fmx, fmy]
     pset = list(prm) + [ivm]
 
     def trig_reduce(e):   # c^2 -> 1 - s^2 (the polynomial expansion does not know the identity)
@@ -669,12 +671,23 @@ def emit_single_mf(model):
     text += ["struct SinglePendulumMFSparsity {", "  static constexpr bool dFdx[8] = %s;" % mask("dFdx", 8),
              "  static constexpr bool dM1[4] = %s;" % mask("dM1", 4),
              "  static constexpr unsigned ja_zero_cols = 0x%xu;" % sum(1 << c for c in range(4) if ja_zero[c]), "};",
-             "// the helper terms of the dynamics at a state: tv = tanh(b_x' / max(v_mu_b, 1e-6)), n = |p_1'| (inv_n its reciprocal, 0 at",
+             "// the helper terms of the dynamics at a state: tv = tanh(b_x' / max(v_mu_b, 1e-6)) and its slope sech2 (where the scalar type",
+             "// has the split tanh, Math<R>::tanh_parts, as 4 e^-2|x| / (1 + e^-2|x|)^2: full relative accuracy where 1 - tanh^2 cancels -- a",
+             "// saturated friction term with a tiny v_mu_b multiplies that slope by up to 1e6), n = |p_1'| (inv_n its reciprocal, 0 at",
              "// rest: the |v|^2 > 0 guard; WITH_J = false skips it), the bumper springs' compressions and their 0 / 1 slopes",
              "template <typename R, bool WITH_J>",
              "__device__ __forceinline__ void single_pendulum_mf_helpers(const SinglePendulumMFConsts<R>& K, const R s, const R c, const R b_x, "
-             "const R b_x_dot, const R th_1_dot, R& tv, R& n, R& inv_n, R& sr, R& sl, R& on_r, R& on_l, R& vx, R& vy) {",
-             "  tv = Math<R>::tanh_scaled(b_x_dot, K.ivm, K.tanh_k2);",
+             "const R b_x_dot, const R th_1_dot, R& tv, R& sech2, R& n, R& inv_n, R& sr, R& sl, R& on_r, R& on_l, R& vx, R& vy) {",
+             "  if constexpr (Math<R>::kMergedReciprocals) {",
+             "    R num, den, e2;",
+             "    Math<R>::tanh_parts(b_x_dot * K.ivm, num, den, e2);",
+             "    const R iden = Math<R>::rcp(den);",
+             "    tv = __builtin_copysign(num * iden, b_x_dot);",
+             "    sech2 = R(4) * e2 * (iden * iden);",
+             "  } else {",
+             "    tv = Math<R>::tanh_scaled(b_x_dot, K.ivm, K.tanh_k2);",
+             "    sech2 = R(1) - tv * tv;",
+             "  }",
              "  const R e_r = b_x - K.x_s, e_l = -K.x_s - b_x;  // strict comparisons, as the reference's generated branches",
              "  const bool is_r = R(0) < e_r, is_l = R(0) < e_l;",
              "  sr = is_r ? e_r : R(0);", "  sl = is_l ? e_l : R(0);", "  on_r = is_r ? R(1) : R(0);", "  on_l = is_l ? R(1) : R(0);",
@@ -691,7 +704,7 @@ def emit_single_mf(model):
         tag = "ext" if with_ext else "noext"
         text += ["template <typename R, bool WITH_J>",
                  "__device__ __forceinline__ void single_pendulum_mf_terms_%s(const SinglePendulumMFConsts<R>& K, const R s, const R c, "
-                 "const R tv, const R n, const R inv_n, const R sr, const R sl, const R on_r, const R on_l, const R vx, const R vy, const R b_x_dot, "
+                 "const R tv, const R sech2, const R n, const R inv_n, const R sr, const R sl, const R on_r, const R on_l, const R vx, const R vy, const R b_x_dot, "
                  "const R th_1_dot, const R u, const R f_b_x, const R f_m1_x, const R f_m1_y, R* M, R* F, R* dFdx, R* dM1) {" % tag]
         for i, sym in enumerate(const_syms):
             if sym in used:
@@ -724,7 +737,7 @@ def emit_single_mf(model):
                 continue
             if e != 0:
                 text.append("    %s = %s;" % (nm, pr.doprint(e)))
-        text += ["  }", "  (void)s; (void)c; (void)tv; (void)n; (void)inv_n; (void)sr; (void)sl; (void)on_r; (void)on_l; (void)vx; (void)vy; (void)b_x_dot; "
+        text += ["  }", "  (void)s; (void)c; (void)tv; (void)sech2; (void)n; (void)inv_n; (void)sr; (void)sl; (void)on_r; (void)on_l; (void)vx; (void)vy; (void)b_x_dot; "
                  "(void)th_1_dot; (void)u; (void)f_b_x; (void)f_m1_x; (void)f_m1_y; (void)dFdx; (void)dM1;", "}"]
         dfdu = [red[names.index("dFdu[%d]" % i)] for i in range(2)]
         assert dfdu[0] == 1 and dfdu[1] == 0, dfdu   # the control acts on the base only: da/du = M^-1 e_0 (the solver assumes it)
