@@ -40,7 +40,7 @@ SYMBOLS = [
     "cpmpc_profile_enable", "cpmpc_profile_reset", "cpmpc_profile_read", "cpmpc_kernel_name",
     "cpmpc_sharded_create", "cpmpc_sharded_destroy", "cpmpc_sharded_num_shards", "cpmpc_sharded_device", "cpmpc_sharded_peer_access",
     "cpmpc_sharded_handle", "cpmpc_sharded_range", "cpmpc_sharded_reset", "cpmpc_sharded_step_batch_host",
-    "cpmpc_sharded_step_batch", "cpmpc_sharded_create_ex", "cpmpc_sharded_previous_solution_batch",
+    "cpmpc_sharded_step_batch", "cpmpc_sharded_create_ex", "cpmpc_sharded_previous_solution_batch", "cpmpc_sharded_horizon_beyond_parity",
     "cpmpc_sharded_set_previous_solution", "cpmpc_sharded_set_previous_solution_host", "cpmpc_sharded_get_solution",
     "cpmpc_sharded_get_solution_host", "cpmpc_sharded_step_batch_host_in", "cpmpc_sharded_step_batch_ex",
     "cpmpc_step_batch_host_in", "cpmpc_set_host_chunk", "cpmpc_host_register", "cpmpc_host_unregister",
@@ -265,6 +265,8 @@ def load():
     L.cpmpc_sharded_step_batch_host.argtypes = [vp, i64, _dp, _dp, dbl, C.POINTER(StepHostOutputs)]
     L.cpmpc_sharded_step_batch.argtypes = [vp, i64, vp, _dp, dbl, C.POINTER(StepOutputs), vp]
     L.cpmpc_sharded_create_ex.argtypes = [C.POINTER(CreateInfo), C.POINTER(C.c_int), i32, C.POINTER(vp)]
+    L.cpmpc_sharded_horizon_beyond_parity.argtypes = [vp]
+    L.cpmpc_sharded_horizon_beyond_parity.restype = i32
     L.cpmpc_sharded_previous_solution_batch.argtypes = [vp]
     L.cpmpc_sharded_previous_solution_batch.restype = i64
     L.cpmpc_sharded_set_previous_solution.argtypes = [vp, i64, vp, vp]

@@ -1223,6 +1223,10 @@ extern "C" int cpmpc_sharded_reset(cpmpc_sharded* s) {
   return CPMPC_OK;
 }
 extern "C" int64_t cpmpc_sharded_previous_solution_batch(const cpmpc_sharded* s) { return s ? s->warm_total : 0; }
+// every shard was created from the same parameters: the status of shard 0 is the handle's
+extern "C" int cpmpc_sharded_horizon_beyond_parity(const cpmpc_sharded* s) {
+  return (s && !s->shards.empty()) ? cpmpc_horizon_beyond_parity(s->shards[0].h) : -1;
+}
 
 static int sharded_check(const cpmpc_sharded* s, int64_t B) {
   if (B < 1) return fail(CPMPC_ERR_INVALID_ARG, "B must be >= 1");

@@ -172,7 +172,8 @@ PYBIND11_MODULE(pypendulum, m) {
       .def("previous_solution_batch", &ShardedOptimization::PreviousSolutionBatch)
       .def("num_shards", &ShardedOptimization::NumShards)
       .def("device_of_shard", &ShardedOptimization::DeviceOfShard)
-      .def("shard_range", &ShardedOptimization::ShardRange);
+      .def("shard_range", &ShardedOptimization::ShardRange)
+      .def_property_readonly("horizon_beyond_parity", &ShardedOptimization::HorizonBeyondParity);
 
   py::class_<Vector2>(m, "Vector2")
       .def(py::init<double, double>())

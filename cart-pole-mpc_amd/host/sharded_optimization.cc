@@ -77,6 +77,7 @@ ShardedOptimization::~ShardedOptimization() { cpmpc_sharded_destroy(sharded_); }
 
 void ShardedOptimization::Reset() { cpmpc_sharded_reset(sharded_); }
 
+bool ShardedOptimization::HorizonBeyondParity() const noexcept { return cpmpc_sharded_horizon_beyond_parity(sharded_) == 1; }
 std::size_t ShardedOptimization::NumShards() const noexcept {
   return static_cast<std::size_t>(cpmpc_sharded_num_shards(sharded_));
 }

@@ -53,6 +53,8 @@ class ShardedOptimization {
   void SetHostChunk(std::size_t problems);
   std::size_t Dim() const noexcept;
 
+  // the horizon exceeds cpmpc_max_parity_horizon() (include/cpmpc.h: cpmpc_horizon_beyond_parity), as Optimization::HorizonBeyondParity
+  [[nodiscard]] bool HorizonBeyondParity() const noexcept;
   std::size_t NumShards() const noexcept;
   int DeviceOfShard(std::size_t shard) const noexcept;
   // columns [first, second) of a B-controller batch that `shard` solves

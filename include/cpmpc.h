@@ -437,6 +437,8 @@ int cpmpc_sharded_reset(cpmpc_sharded* s);                             /* Optimi
  *   - a step that fails part-way resets every shard (no mixture of old and new solutions survives).
  * Never a silent misalignment.  The hand-over is synchronous and costs one gather + one scatter of [dim][n] scalars. */
 int64_t cpmpc_sharded_previous_solution_batch(const cpmpc_sharded* s);
+/* cpmpc_horizon_beyond_parity() of the sharded handle (its shards share one parameter set); -1: null handle */
+int cpmpc_sharded_horizon_beyond_parity(const cpmpc_sharded* s);
 /* Optimization::SetPreviousSolution over all shards (optimization.hpp:86-89): z [dim][B] on the ROOT device in the
  * handle's dtype (asynchronous on `stream`, a stream of the root device), or HOST doubles.  Replaces every warm start. */
 int cpmpc_sharded_set_previous_solution(cpmpc_sharded* s, int64_t B, const void* z, void* stream);

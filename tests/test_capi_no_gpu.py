@@ -145,6 +145,7 @@ def test_long_horizons_are_accepted_and_refused_only_when_asked(lib, pkg, capfd)
     assert lib.cpmpc_max_parity_horizon() == pytest.approx(1.0)
     assert lib.cpmpc_horizon_beyond_parity(None) == -1   # the per-handle status (round 6) of no handle
     assert lib.cpmpc_get_solver_opts(None, None, 0) == pkg.capi.ERR_INVALID_ARG
+    assert lib.cpmpc_sharded_horizon_beyond_parity(None) == -1
     h = C.c_void_p()
     past = (pkg.capi.OK, pkg.capi.ERR_NO_DEVICE)
     for over in (dict(window_length=160), dict(window_length=120, state_spacing=12), dict(control_dt=0.05)):

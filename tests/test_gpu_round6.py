@@ -115,6 +115,9 @@ def test_horizon_beyond_parity_is_a_per_handle_status(pkg, orc):
     assert opt.horizon_beyond_parity
     out = opt.step(pyp.SingleCartPoleState(0.0, np.pi / 2 - 0.1, 0.0, 0.0), pyp.SingleCartPoleParams(*DYN_UI), 0.0)
     assert "cpmpc_max_parity_horizon" in out.solver_summary() and len(out.u) == 160
+    assert pyp.ShardedOptimization(op, 8, [0, 0]).horizon_beyond_parity
+    op.window_length = 40
+    assert not pyp.ShardedOptimization(op, 8, [0, 0]).horizon_beyond_parity
 
 
 def test_wide_qp_is_a_property_of_the_handle_not_of_the_step(pkg):
