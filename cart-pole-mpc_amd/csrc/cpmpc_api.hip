@@ -232,7 +232,10 @@ static int create_impl(const cpmpc_params* params, const cpmpc_solver_opts* opts
   // further passes change nothing (the refined solve and a dense pivoted one are then both at the problem's conditioning)
   s->refine_qp = (flags & CPMPC_CREATE_REFINE_QP) != 0 ||
                  (!(flags & CPMPC_CREATE_NO_REFINE_QP) && (params->u_cost_weight < kRefineBelowUCostWeight || s->beyond_parity));
-  s->refine_passes = 1;
+  // split pipeline: one pass; two beyond the parity horizon (tools/long_horizon_refine_study.py, first QP of 300 cold starts at
+  // 1.6 s against a long-double solve: worst lane 3.5e-5 condensed, 1.6e-11 after one pass, 1.2e-13 after two -- the dense
+  // pivoted LU of the CPU check: 1.1e-12; further passes change nothing)
+  s->refine_passes = s->beyond_parity ? 2 : 1;
   if (const char* e = getenv("CPMPC_QP_REFINE_PASSES")) {   // diagnostic (tools/long_horizon_gpu_probe.py): passes of the split pipeline
     const int n = atoi(e);
     if (n >= 1 && n <= 16) s->refine_passes = n;
