@@ -166,6 +166,11 @@ static inline bool use_fused(const cpmpc_solver* s) {
   if (s->pipeline == CPMPC_PIPELINE_AUTO && s->model == CPMPC_MODEL_DOUBLE && s->dtype == CPMPC_F64 &&
       3 * fused_wave_lds_bytes(s) > 160u * 1024u)
     return false;
+  // AUTO beyond the parity horizon (fp64; round 6): the split pipeline, whose QP kernel runs TWO refinement passes there -- from
+  // the second pass on the refined condensed solve is more accurate than a dense pivoted LU on the worst cold starts
+  // (kernels at fault on 1 lane of 8 192 at 1.6 s, like the CPU check; the fused kernel's one pass: 3).
+  // Throughput is not the bar there; cpmpc_set_pipeline(FUSED) is the caller's to choose.
+  if (s->pipeline == CPMPC_PIPELINE_AUTO && s->beyond_parity && s->dtype == CPMPC_F64 && s->refine_qp) return false;
   return true;
 }
 

@@ -225,10 +225,11 @@ int cpmpc_wide_qp(const cpmpc_solver* s);
 double cpmpc_max_parity_horizon(void);
 /* 1: this handle's horizon window_length * control_dt is beyond cpmpc_max_parity_horizon() -- a PER-HANDLE status (round 6;
  * the once-per-process line on stderr is easy to miss in a notebook): such a handle is solved as asked, with the QP
- * refinement of CPMPC_CREATE_REFINE_QP on by default (CPMPC_F64), and on a few cold starts in 10^4 far from the optimum its
- * controls may differ from a full-space solve by more than 1e-5 (measured at 1.6 s, three iterations: 3 of 8 192 lanes
- * with the kernels at fault by the extended-precision arbiter, 34 without the refinement; a dense pivoted solve in double is
- * itself up to 6.6e-5 from the extended-precision answer there).  pendulum::Optimization::HorizonBeyondParity(), the
+ * refinement of CPMPC_CREATE_REFINE_QP on by default (CPMPC_F64) and, under CPMPC_PIPELINE_AUTO, by the split pipeline with
+ * two refinement passes; on a few cold starts in 10^4 far from the optimum its controls may still differ from a full-space
+ * solve by more than 1e-5 (measured at 1.6 s, three iterations: 1 of 8 192 lanes with the kernels at fault by the
+ * extended-precision arbiter and 1 with the CPU check at fault, 34 / 0 without the refinement; a dense pivoted solve in
+ * double is itself up to 6.6e-5 from the extended-precision answer there).  pendulum::Optimization::HorizonBeyondParity(), the
  * `horizon_beyond_parity` attribute of pypendulum.Optimization and a line in solver_summary() carry it to the caller.
  * 0: within the bound; -1: null handle.  Replaces nothing in the reference (optimization.cc:13-22 accepts any horizon). */
 int cpmpc_horizon_beyond_parity(const cpmpc_solver* s);

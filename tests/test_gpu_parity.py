@@ -663,6 +663,9 @@ def test_long_horizons_fused(pkg, orc, over):
             pkg.BatchOptimization(pkg.default_params(**over), max_batch=96, dtype=torch.float64, device=0, strict_horizon=True)
         assert exc.value.code == pkg.capi.ERR_UNSUPPORTED and "STRICT_HORIZON" in str(exc.value)
     opt = pkg.BatchOptimization(pkg.default_params(**over), max_batch=96, dtype=torch.float64, device=0)
+    # round 6: beyond the parity horizon AUTO takes the split pipeline (two passes of QP refinement there); the fused kernel on request
+    assert opt.pipeline() == ("split" if long_h else "fused")
+    opt.set_pipeline("fused")
     assert opt.pipeline() == "fused"
     out = opt.step(T(x0), DYN_UI, 0.0)
     u_cpu, _, st_cpu, it_cpu, _ = orc.step_batch_cold(orc.default_opt_params(**over), DYN_UI, 0.0, x0)

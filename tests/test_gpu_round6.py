@@ -98,7 +98,7 @@ def test_horizon_beyond_parity_is_a_per_handle_status(pkg, orc):
     assert not o.horizon_beyond_parity and "cpmpc_max_parity_horizon" not in o.solver_summary()
     over = dict(window_length=160, max_iterations=3)
     long_ = pkg.BatchOptimization(pkg.default_params(**over), max_batch=64, dtype=torch.float64, device=0)
-    assert long_.horizon_beyond_parity and long_.refines_qp
+    assert long_.horizon_beyond_parity and long_.refines_qp and long_.pipeline() == "split"   # AUTO: two-pass split kernel there
     o = long_.step(T(x0), DYN_UI, 0.0)
     assert o.horizon_beyond_parity and "cpmpc_max_parity_horizon" in o.solver_summary()
     u_cpu, _, st_cpu, _, _ = orc.step_batch_cold(orc.default_opt_params(**over), DYN_UI, 0.0, x0)

@@ -25,8 +25,8 @@ res = []
 for tag, over, seed in CASES:
     x0 = states(np.random.default_rng(500 + seed + SEED_SHIFT), B)
     u_cpu, _, st_cpu, it_cpu, _ = orc.step_batch_cold(orc.default_opt_params(**over), DYN_UI, 0.0, x0, num_threads=THREADS)
-    for pipe in ("fused", "split"):
-        for refine in (False, True):
+    for pipe in ("auto", "fused", "split"):
+        for refine in ((None,) if pipe == "auto" else (False, True)):   # auto: the handle as a caller gets it (refinement on, split)
             opt = pkg.BatchOptimization(pkg.default_params(**over), max_batch=B, dtype=torch.float64, device=0,
                                         allow_long_horizon=True, refine_qp=refine)
             opt.set_pipeline(pipe)
