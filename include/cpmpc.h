@@ -486,7 +486,12 @@ enum {
  *   CPMPC_PIPELINE_FUSED  one launch for all iterations, a problem spread over its S-1 shooting intervals' lanes,
  *                         sensitivities and QP factors in registers and LDS.  Both models; any state_spacing whose
  *                         interval count S-1 is one of 2, 4, 5, 8, 10, 16 and whose per-wave LDS fits 64 KB;
- *   CPMPC_PIPELINE_AUTO   fused where built, else split (default; the 6-state model in fp64 stays on split).
+ *   CPMPC_PIPELINE_AUTO   fused where built, else split (default).  Two exceptions, both fp64: the 6-state model where fewer
+ *                         than three of its fused waves fit a CU's LDS (state_spacing 20), and -- round 6 -- any handle whose
+ *                         horizon is beyond cpmpc_max_parity_horizon(): the split QP kernel runs two refinement passes there
+ *                         (cpmpc_horizon_beyond_parity).
+ * The handle's options hold in either pipeline: cpmpc_refines_qp(), cpmpc_wide_qp() and cpmpc_get_solver_opts() tell what it
+ * uses, cpmpc_get_pipeline() which pipeline its next step takes.
  * Returns CPMPC_ERR_UNSUPPORTED if FUSED is requested for a configuration it is not built for. */
 enum { CPMPC_PIPELINE_AUTO = 0, CPMPC_PIPELINE_SPLIT = 1, CPMPC_PIPELINE_FUSED = 2 };
 int cpmpc_set_pipeline(cpmpc_solver* s, int mode);
